@@ -1,0 +1,248 @@
+"""Generate the AR golden fixtures by running the REFERENCE itself (CPU, eager).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+What comes from the reference: `AsteroidTTSInstruct.forward`
+(/root/reference/modeling_asteroid.py:337-426, with HF Qwen3Model underneath)
+and the HF logits processors.  What is restated here: the body of
+`CustomMixin._sample` (modeling_asteroid.py:83-169) — transformers 5.15 removed
+`_get_initial_cache_position` and the 4.53.2 `prepare_inputs_for_generation`
+slicing that the original needs, so the loop below follows the
+reference line by line and calls the reference forward for every logit.
+
+Shims (import-time only): an empty `liger_kernel` module tree (training-only
+import at modeling_asteroid.py:14) and a list->dict conversion of
+`_tied_weights_keys` for transformers 5.x.
+
+Only data is written: inputs, expected ids, selected logits (bf16 bit patterns)
+and the (config, seed) needed to regenerate the weights with mtts.synth.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "moss-ttsd_amd"))
+from mtts import synth  # noqa: E402
+
+for n in ["liger_kernel", "liger_kernel.transformers", "liger_kernel.transformers.model",
+          "liger_kernel.transformers.model.loss_utils"]:
+    sys.modules[n] = types.ModuleType(n)
+sys.modules["liger_kernel.transformers.model.loss_utils"].LigerForCausalLMLoss = None
+sys.path.insert(0, "/root/reference")
+import modeling_asteroid as ma  # noqa: E402
+from transformers.cache_utils import DynamicCache  # noqa: E402
+from transformers.generation.logits_process import (  # noqa: E402
+    LogitsProcessorList, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+    TopKLogitsWarper, TopPLogitsWarper)
+
+
+class RefModel(ma.AsteroidTTSInstruct):
+    @property
+    def _tied_weights_keys(self):
+        return self.__dict__.get("_twk", {})
+
+    @_tied_weights_keys.setter
+    def _tied_weights_keys(self, v):
+        if isinstance(v, list):
+            v = {k: k.replace("lm_heads", "model.embedding_list") for k in v}
+        self.__dict__["_twk"] = v
+
+    def tie_weights(self, *a, **kw):
+        for i in range(self.config.channels):
+            self.lm_heads[i].weight = self.model.embedding_list[i].weight
+
+
+def build_reference(cfg, weights, dtype):
+    hf = ma.AsteroidTTSConfig(
+        vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+        intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+        num_attention_heads=cfg["num_attention_heads"], num_key_value_heads=cfg["num_key_value_heads"],
+        head_dim=cfg["head_dim"], max_position_embeddings=cfg["max_position_embeddings"],
+        rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"], tie_word_embeddings=True,
+        speech_token_range=cfg["speech_token_range"], pad_token_id=cfg["pad_token_id"],
+        eos_token_id=cfg["eos_token_id"], attn_implementation="eager",
+        channels=cfg["channels"], speech_pad_token=cfg["speech_pad_token"],
+        speech_vocab_size=cfg["speech_vocab_size"])
+    m = RefModel(hf).eval()
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("embed_tokens" in k or "lm_heads" in k for k in missing), missing
+    m.tie_weights()
+    m = m.to(dtype)
+    # from_pretrained(torch_dtype=...) (reference generation_utils.py:18) leaves the non-persistent
+    # RoPE inv_freq buffer in fp32; a blanket .to(bf16) would round it, so restore it.
+    rot = m.model.language_model.rotary_emb
+    inv, _ = rot.compute_default_rope_parameters(hf)
+    rot.inv_freq = inv.float()
+    rot.original_inv_freq = inv.float().clone()
+    return m
+
+
+@torch.no_grad()
+def ref_sample_loop(model, input_ids, attention_mask, max_length, layers=None, keep_logits=None):
+    """Restatement of modeling_asteroid.py:83-169 (greedy / processor path)."""
+    cfgm = model.config
+    channels = cfgm.channels
+    speech_pad_idx = cfgm.speech_pad_token
+    B = input_ids.shape[0]
+    unfinished = torch.ones(B, dtype=torch.long)
+    nas = -1 * torch.ones(B, dtype=torch.long)
+    tf_inputs = input_ids[:]
+    input_ids = input_ids[:, :-(channels - 1)]
+    attention_mask = attention_mask[:, :-(channels - 1)]
+    base_length = input_ids.shape[1]
+    cache = DynamicCache(config=cfgm)
+    procs = [LogitsProcessorList() for _ in range(channels)]
+    for i, lc in enumerate(layers or []):
+        if lc.get("repetition_penalty") is not None:
+            procs[i].append(RepetitionPenaltyLogitsProcessor(penalty=lc["repetition_penalty"]))
+        if lc.get("temperature") is not None:
+            procs[i].append(TemperatureLogitsWarper(temperature=lc["temperature"]))
+        if lc.get("top_k") is not None:
+            procs[i].append(TopKLogitsWarper(top_k=lc["top_k"]))
+        if lc.get("top_p") is not None:
+            procs[i].append(TopPLogitsWarper(top_p=lc["top_p"]))
+    logits_log, margins = [], []
+    fed = 0
+    while True:
+        # transformers 4.53.2 prepare_inputs_for_generation semantics
+        pos = attention_mask.long().cumsum(-1) - 1
+        pos.masked_fill_(attention_mask == 0, 1)
+        out = model(input_ids=input_ids[:, fed:], attention_mask=attention_mask,
+                    position_ids=pos[:, fed:], past_key_values=cache, use_cache=True, return_dict=True)
+        fed = input_ids.shape[1]
+        nlog = [l[:, -1, :].clone().float() for l in out.logits_all]
+        for i, cl in enumerate(nlog):
+            if i != 0 and input_ids.shape[1] + 1 > tf_inputs.shape[1] - 7 + i:
+                cl[:, 1024] = -torch.inf
+            if i == 0 and input_ids.shape[1] + 1 <= tf_inputs.shape[1]:
+                cl[:, 152694] = -torch.inf
+        if keep_logits is not None:
+            logits_log.append([keep_logits(i, l) for i, l in enumerate(nlog)])
+        scores = [procs[i](input_ids[..., i], l) for i, l in enumerate(nlog)]
+        nxt = torch.stack([torch.argmax(s, dim=-1) for s in scores], dim=-1)
+        top2 = torch.stack([torch.topk(s, 2, dim=-1).values for s in scores], dim=1)  # [B,C,2]
+        mg = ((top2[..., 0] - top2[..., 1]) / top2[..., 0].abs().clamp_min(1e-6))
+        raw = nxt.clone()
+        idx = (~model.is_speech_token(nxt[:, 0])) & (nas < 0)
+        nas[idx] = channels - 1
+        if input_ids.shape[1] + 1 <= tf_inputs.shape[1]:
+            i = input_ids.shape[1] + 1 - base_length
+            nxt[:, i:] = tf_inputs[:, input_ids.shape[1], i:]
+        mask = (nas > 0) & (nas < 7)
+        if mask.any().item():
+            nxt[mask, 0] = cfgm.eos_token_id
+            for i in range(1, channels):
+                nxt[mask & (nas < channels - i), i] = speech_pad_idx
+        for i in range(channels):
+            pddp = cfgm.eos_token_id if i == 0 else speech_pad_idx
+            nxt[:, i] = nxt[:, i] * unfinished + pddp * (1 - unfinished)
+        # a decision is "used" when the argmax survived teacher forcing / flush / finished padding
+        used = (raw == nxt) & (unfinished[:, None] == 1)
+        step_i = input_ids.shape[1] - base_length
+        used[:, step_i + 1:] = False if step_i < channels - 1 else used[:, step_i + 1:]
+        margins.append(torch.where(used, mg, torch.full_like(mg, 9.0)).numpy())
+        input_ids = torch.cat([input_ids, nxt[:, None, :]], dim=1)
+        attention_mask = torch.cat([attention_mask, attention_mask.new_ones(B, 1)], dim=1)
+        nas = torch.where(nas > 0, nas - 1, nas)
+        stopping = (input_ids.shape[1] >= max_length) | (input_ids[:, -1, 0] == cfgm.eos_token_id) | (nas == 0)
+        unfinished = unfinished & ~stopping
+        unfinished = unfinished | (nas > 0)
+        if unfinished.max() == 0:
+            break
+    return input_ids.numpy(), logits_log, np.stack(margins)
+
+
+def bf16_bits(t):
+    return t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+CH0_LO = 151600  # slice of channel-0 logits kept in fixtures (covers speech range + EOS)
+
+
+def keep(i, l):
+    return bf16_bits(l[:, CH0_LO:]) if i == 0 else bf16_bits(l)
+
+
+def make_case(name, cfg_over, wkw, seed, batch, prompt_len, audio_frac, max_new, layers=None,
+              dtype=torch.bfloat16, ragged=True, keep_steps=12):
+    cfg = synth.tiny(**cfg_over)
+    w = synth.synth_weights(cfg, seed, bf16=(dtype == torch.bfloat16), **wkw)
+    model = build_reference(cfg, w, dtype)
+    ids, mask = synth.synth_prompts(cfg, seed + 1, batch, prompt_len, audio_frac, ragged)
+    max_length = ids.shape[1] + max_new
+    out, logs, margins = ref_sample_loop(model, torch.from_numpy(ids), torch.from_numpy(mask),
+                                         max_length, layers, keep)
+    steps = out.shape[1] - (ids.shape[1] - 7)
+    d = dict(cfg=json.dumps(cfg), wkw=json.dumps(wkw), seed=seed, input_ids=ids, attention_mask=mask,
+             max_length=max_length, out_ids=out, margins=margins.astype(np.float32),
+             layers=json.dumps(layers or []), dtype="bf16" if dtype == torch.bfloat16 else "fp32",
+             transformers_version=__import__("transformers").__version__, ch0_lo=CH0_LO)
+    for s in range(min(keep_steps, steps)):
+        d[f"logits0_step{s}"] = logs[s][0]
+        d[f"logits17_step{s}"] = np.stack(logs[s][1:], axis=0)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    # free-running argmaxes only (teacher-forced slots carry no decision)
+    print(f"{name}: T={ids.shape[1]} steps={steps} out={out.shape} min_rel_margin={margins.min():.4f} "
+          f"lens={[int((out[b, :, 0] != cfg['eos_token_id']).sum()) for b in range(batch)]}")
+    return margins.min()
+
+
+def processors_case():
+    """HF processor outputs on fixed logits/history (pins oracle.apply_processors)."""
+    rng = np.random.default_rng(7)
+    B, V, n = 3, 1025, 40
+    logits = torch.from_numpy(rng.standard_normal((B, V)).astype(np.float32) * 2).bfloat16().float()
+    hist = torch.from_numpy(rng.integers(0, V, (B, n)))
+    out = {"logits": logits.numpy(), "history": hist.numpy()}
+    cfgs = [dict(repetition_penalty=1.1), dict(temperature=0.8), dict(top_k=50), dict(top_p=0.9),
+            dict(repetition_penalty=1.2, temperature=0.9, top_k=30, top_p=0.8),
+            dict(temperature=1.0, top_k=50, top_p=0.95)]
+    for j, lc in enumerate(cfgs):
+        pl = LogitsProcessorList()
+        if "repetition_penalty" in lc:
+            pl.append(RepetitionPenaltyLogitsProcessor(penalty=lc["repetition_penalty"]))
+        if "temperature" in lc:
+            pl.append(TemperatureLogitsWarper(temperature=lc["temperature"]))
+        if "top_k" in lc:
+            pl.append(TopKLogitsWarper(top_k=lc["top_k"]))
+        if "top_p" in lc:
+            pl.append(TopPLogitsWarper(top_p=lc["top_p"]))
+        out[f"cfg{j}"] = json.dumps(lc)
+        out[f"scores{j}"] = pl(hist, logits.clone()).numpy()
+    np.savez_compressed(os.path.join(HERE, "processors.npz"), **out)
+    print("processors: ok")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["all"]
+    if "all" in which or "proc" in which:
+        processors_case()
+    if "all" in which or "ar" in which:
+        lo = dict(emb_row_sigma=0.6, speech_boost=3.2, eos_boost=3.2)
+        hi = dict(emb_row_sigma=0.6, speech_boost=4.0, eos_boost=11.0)
+        # (ii)+(iv)+(i)+(v): text-only prompts, ragged left pads; row 1 picks a non-speech id at
+        # step 25 -> EOS flush, then finished-row padding while rows 0/2 run to max_length
+        make_case("ar_text_ragged", {}, lo, 103, 3, 24, 0.0, 40)
+        # two rows flush from step 0 (shortest possible dialogue), one runs on
+        make_case("ar_flush0", {}, lo, 101, 3, 24, 0.0, 24)
+        # (iii) audio-prompt tail: teacher-forced codes in the first 7 steps
+        make_case("ar_audio_tail", {}, hi, 200, 2, 40, 0.5, 32)
+        # group size 4, single row, no padding
+        make_case("ar_gqa4", dict(num_attention_heads=8, num_key_value_heads=2, hidden_size=512,
+                                  intermediate_size=768), hi, 301, 1, 20, 0.4, 24, ragged=False)
+        # fp32 run of the first case: tight-tolerance pin of the oracle's structure
+        make_case("ar_text_ragged_fp32", {}, lo, 103, 3, 24, 0.0, 40, dtype=torch.float32)
+        # processors on the greedy path (repetition penalty changes the argmax)
+        make_case("ar_rep_penalty", {}, hi, 404, 2, 24, 0.3, 24,
+                  layers=[dict(repetition_penalty=1.3)] * 8)
