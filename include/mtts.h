@@ -1,0 +1,143 @@
+/*
+ * mtts.h -- C ABI of libmtts.so, the MI355X-native engine under the
+ * MOSS-TTSD hot path (AsteroidTTSInstruct decode + XY_Tokenizer decode).
+ *
+ * The reference has no FFI of its own: its boundary is the Python surface
+ *   model.generate(input_ids[B,T,8], attention_mask[B,T])   generation_utils.py:406-409
+ *   CustomMixin._sample                                      modeling_asteroid.py:53-197
+ *   AsteroidTTSInstruct.forward (inference branch)           modeling_asteroid.py:337-380,411-426
+ *   spt.decode(codes_list)                                   XY_Tokenizer/xy_tokenizer/model.py:195-256
+ * Each entry point below names the reference code it replaces.  The Python
+ * mirror of that surface (moss-ttsd_amd/modeling_asteroid.py etc.) binds these
+ * symbols with ctypes; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every `dev_` pointer is
+ * device memory of the engine's GPU (caller-owned: torch tensors); `host_`
+ * pointers are host memory; `stream` is a hipStream_t passed as void* (NULL =
+ * default stream).  Every function returns 0 on success or a negative
+ * MTTS_E* code; mtts_last_error() gives the message of the calling thread's
+ * last failure.  One engine = one device; an engine is not thread-safe.
+ * No C++ exception crosses this boundary.
+ */
+#ifndef MTTS_H
+#define MTTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTTS_OK 0
+#define MTTS_EINVAL (-1)      /* bad argument / unsupported shape */
+#define MTTS_EHIP (-2)        /* HIP runtime error */
+#define MTTS_ENOMEM (-3)      /* KV page pool or workspace exhausted */
+#define MTTS_ESTATE (-4)      /* call sequence error (e.g. decode before prefill) */
+
+#define MTTS_CHANNELS 8
+
+/* Fields of AsteroidTTSConfig / Qwen3Config the path reads
+ * (modeling_asteroid.py:17-28; transformers Qwen3Config). */
+typedef struct MttsConfig {
+    int32_t vocab_size;            /* channel-0 vocabulary */
+    int32_t hidden_size;
+    int32_t intermediate_size;
+    int32_t num_hidden_layers;
+    int32_t num_attention_heads;
+    int32_t num_key_value_heads;
+    int32_t head_dim;              /* must be 128 */
+    int32_t channels;              /* must be 8 */
+    int32_t speech_vocab_size;     /* 1025 */
+    int32_t speech_pad_token;      /* 1024 */
+    int32_t speech_range_lo;       /* speech_token_range[0] */
+    int32_t speech_range_hi;       /* speech_token_range[1] */
+    int32_t eos_token_id;
+    int32_t max_position;          /* rows in the RoPE table */
+    float rms_norm_eps;
+    int32_t max_batch;             /* sequences resident at once */
+    int32_t max_seq_len;           /* real tokens per sequence the KV pool is sized for */
+} MttsConfig;
+
+/* generation_config.layers[i] / do_samples[i] (modeling_asteroid.py:95-106).
+ * A field <= 0 (or top_k == 0) means "processor absent". */
+typedef struct MttsSamplerCfg {
+    int32_t do_sample;
+    int32_t top_k;
+    float top_p;
+    float one_minus_top_p;   /* (float)(1.0 - (double)top_p): HF compares cum <= 1 - top_p with the scalar cast to fp32 */
+    float temperature;
+    float repetition_penalty;
+} MttsSamplerCfg;
+
+typedef struct MttsEngine MttsEngine;
+
+const char* mtts_last_error(void);
+int32_t mtts_version(void);
+
+/* ---- engine lifetime ---------------------------------------------------- */
+int32_t mtts_engine_create(const MttsConfig* cfg, int32_t device, MttsEngine** out);
+int32_t mtts_engine_destroy(MttsEngine* e);
+
+/* Weight binding: state-dict name (reference naming, e.g.
+ * "model.language_model.layers.3.self_attn.q_proj.weight",
+ * "model.embedding_list.0.weight", "model.language_model.norm.weight") ->
+ * bf16 row-major device tensor.  The engine re-lays the matrix out into its
+ * MFMA-fragment order in its own memory; the caller's tensor may be freed
+ * after the call returns (stream-ordered).  Replaces from_pretrained's
+ * parameter materialisation (generation_utils.py:18). */
+int32_t mtts_bind_weight(MttsEngine* e, const char* name, const void* dev_bf16,
+                         int64_t rows, int64_t cols, void* stream);
+/* RoPE table cos|sin, bf16 [max_position][64] each, computed by the host the
+ * way Qwen3RotaryEmbedding does (fp32 -> bf16). */
+int32_t mtts_bind_rope(MttsEngine* e, const void* dev_cos_bf16, const void* dev_sin_bf16,
+                       int32_t rows, void* stream);
+int32_t mtts_weights_ready(MttsEngine* e);   /* 0 when every tensor is bound */
+
+/* ---- generation (replaces model.generate -> CustomMixin._sample) --------- */
+/* host_input_ids int64 [B,T,8], host_attention_mask uint8 [B,T] (left padded,
+ * 1 = real).  max_length = HF generation_config.max_length (T + max_new_tokens).
+ * sampler[8], seed: sampling stream (Philox4x32-10).
+ * Prefills the first T-7 slots, then runs the decode loop on the device until
+ * every row is finished.  out: host_out_ids int64 [B, out_capacity, 8] receives
+ * [B, T-7+G, 8]; *out_len = T-7+G.
+ * host_forced (verification hook, may be NULL): int64 [B, forced_len, 8] full
+ * sequences; when given, every step's own decision is written to
+ * host_decisions int64 [G,B,8] and the forced row is appended instead. */
+int32_t mtts_generate(MttsEngine* e, const int64_t* host_input_ids, const uint8_t* host_attention_mask,
+                      int32_t B, int32_t T, int32_t max_length,
+                      const MttsSamplerCfg* sampler, uint64_t seed,
+                      int64_t* host_out_ids, int32_t out_capacity, int32_t* out_len,
+                      const int64_t* host_forced, int32_t forced_len, int64_t* host_decisions,
+                      void* stream);
+
+/* Step-level API (bench + tests): same state as mtts_generate, driven by the host. */
+int32_t mtts_begin(MttsEngine* e, const int64_t* host_input_ids, const uint8_t* host_attention_mask,
+                   int32_t B, int32_t T, int32_t max_length,
+                   const MttsSamplerCfg* sampler, uint64_t seed, void* stream);   /* prefill */
+int32_t mtts_step(MttsEngine* e, int32_t n_steps, void* stream);   /* n x (sample+update, forward); async */
+int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finished, void* stream);
+int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_steps, int32_t* n_steps);
+/* last forward's logits: bf16 bits, channel 0 [B,vocab_size], channels 1..7 [7,B,speech_vocab_size] */
+int32_t mtts_read_logits(MttsEngine* e, uint16_t* host_logits0, uint16_t* host_logits17, void* stream);
+/* name of / time spent in the dominant decode kernel since the last reset, measured with hipEvents
+ * on the launch stream (bench.py's roofline leg). */
+int32_t mtts_profile_enable(MttsEngine* e, int32_t on);
+int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_t* launches, int64_t* bytes);
+
+/* ---- per-kernel entry points (unit tests; device pointers) ---------------- */
+/* Y[32,N] = X[32,K] * W[N,K]^T, bf16 in, fp32 accumulate, bf16 out. */
+int32_t mtts_k_gemm_bf16(const void* dev_w, const void* dev_x, void* dev_y,
+                         int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream);
+/* RMSNorm (Qwen3RMSNorm, modeling_qwen3.py:59-64): x,w bf16 -> y bf16, rows x n. */
+int32_t mtts_k_rmsnorm(const void* dev_x, const void* dev_w, void* dev_y,
+                       int32_t rows, int32_t n, float eps, void* stream);
+/* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
+int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,
+                      const void* dev_history_bitmap, const MttsSamplerCfg* cfg,
+                      int32_t mask_id, uint64_t seed, int32_t step, int32_t channel,
+                      int32_t* dev_tokens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTTS_H */

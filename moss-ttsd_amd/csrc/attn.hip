@@ -1,0 +1,226 @@
+// Paged-KV attention for single-token queries (decode rows and prefill rows alike).
+//
+// Replaces eager_attention_forward (transformers modeling_qwen3.py:185-208) with
+// GQA (repeat_kv :173) over the paged cache.  The reference's eager path rounds
+//   s = bf16(bf16(q.k) * scaling);  p = bf16(softmax_fp32(s));  o = bf16(p @ V)
+// so the kernel keeps those three rounding points: the probabilities need the
+// row-wide max and sum BEFORE they are rounded, hence two streaming passes:
+//   pass A (attn_scores): K stream -> bf16 scores + per-page (max, sumexp)
+//   pass B (attn_pv):     V stream x rounded probabilities -> fp32 partial O
+//   combine:              sum of partial O over chunks -> bf16, X-fragment layout
+// K and V are each read exactly once; scores are 2 B per (head, token) of scratch.
+//
+// HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.
+#include "common.h"
+
+#define ATT_PB 8   // pages per pass-B block (4 waves x 2 pages)
+
+// grid = (ceil(pages/4), nkv, R); block 256 = 4 waves, one page (64 tokens) per wave,
+// one token per lane: K page is [d/8][token][8] so lane t's 16 loads are 16 B each
+// and every wave-instruction covers one contiguous KiB.
+template <int G>
+__global__ __launch_bounds__(256) void attn_scores_kernel(
+    const uint16_t* __restrict__ qbuf, const u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
+    const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
+    int nq, int nkv, float scale, const int32_t* __restrict__ done) {
+    __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
+    if (done && *done) return;
+    const int r = blockIdx.z, kvh = blockIdx.y;
+    const RowMeta m = meta[r];
+    if (m.seq < 0) return;
+    const int len = m.pos + 1;
+    const int npages = (len + MTTS_PAGE - 1) / MTTS_PAGE;
+    if ((int)blockIdx.x * 4 >= npages) return;
+    for (int i = threadIdx.x; i < G * MTTS_HD / 2; i += 256) {
+        int g = i / (MTTS_HD / 2), d2 = i % (MTTS_HD / 2);
+        qs[g][d2] = ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G + g) * (MTTS_HD / 2) + d2];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pg = blockIdx.x * 4 + wave;
+    if (pg >= npages) return;
+    const int page = page_table[(size_t)m.seq * max_pages + pg];
+    const u32x4_t* kp = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+    u32x4_t kv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+    // v_dot2c_f32_bf16: two bf16 products per lane-op, fp32 accumulate, no unpacking.
+    // q is read as a wave-uniform (broadcast) 16-byte LDS word per 8 dims.
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
+            acc[g] = dot2bf(kv[j].x, q.x, acc[g]);
+            acc[g] = dot2bf(kv[j].y, q.y, acc[g]);
+            acc[g] = dot2bf(kv[j].z, q.z, acc[g]);
+            acc[g] = dot2bf(kv[j].w, q.w, acc[g]);
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the q reads from being hoisted into 100s of VGPRs
+    }
+    const int tok = pg * MTTS_PAGE + lane;
+    const bool valid = tok < len;
+    const int Lmax = max_pages * MTTS_PAGE;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int h = kvh * G + g;
+        float s = rbf(rbf(acc[g]) * scale);
+        if (valid) scores[((size_t)r * nq + h) * Lmax + tok] = f2bf(s);
+        float mx = wave_max(valid ? s : -INFINITY);
+        float e = valid ? expf(s - mx) : 0.f;
+        float sm = wave_sum(e);
+        if (lane == 0) {
+            float* st = stats + (((size_t)r * nq + h) * max_pages + pg) * 2;
+            st[0] = mx;
+            st[1] = sm;
+        }
+    }
+}
+
+// grid = (ceil(pages/ATT_PB), nkv, R); block 256.  V page is [token][128]: lane l
+// covers d = 8*(l&15).. of token 4*it + (l>>4): one contiguous KiB per instruction.
+template <int G>
+__global__ __launch_bounds__(256) void attn_pv_kernel(
+    const uint16_t* __restrict__ scores, const float* __restrict__ stats, const u32x4_t* __restrict__ vcache,
+    const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
+    int max_pages, int nchunks_max, int nq, int nkv, const int32_t* __restrict__ done) {
+    __shared__ float red[4][G][MTTS_HD];
+    __shared__ float pbuf[4][G][MTTS_PAGE];
+    if (done && *done) return;
+    const int r = blockIdx.z, kvh = blockIdx.y, chunk = blockIdx.x;
+    const RowMeta m = meta[r];
+    if (m.seq < 0) return;
+    const int len = m.pos + 1;
+    const int npages = (len + MTTS_PAGE - 1) / MTTS_PAGE;
+    if (chunk * ATT_PB >= npages) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Lmax = max_pages * MTTS_PAGE;
+    // row-wide softmax statistics from the per-page (max, sumexp) pairs
+    float M[G], S[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float* st = stats + ((size_t)r * nq + kvh * G + g) * max_pages * 2;
+        float mx = -INFINITY;
+        for (int p = lane; p < npages; p += 64) mx = fmaxf(mx, st[2 * p]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int p = lane; p < npages; p += 64) sm += st[2 * p + 1] * expf(st[2 * p] - mx);
+        sm = wave_sum(sm);
+        M[g] = mx;
+        S[g] = sm;
+    }
+    float acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
+    const int sub = lane >> 4, dl = lane & 15;
+#pragma unroll 1
+    for (int pp = 0; pp < ATT_PB / 4; ++pp) {
+        const int pg = chunk * ATT_PB + wave * (ATT_PB / 4) + pp;
+        if (pg >= npages) break;
+        const int page = page_table[(size_t)m.seq * max_pages + pg];
+        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + sub * 16 + dl;
+        u32x4_t vv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+        // lane t rounds the probability of token pg*64+t once; the 16 lanes that share a
+        // token in the V loop read it back from LDS (same wave: LDS ops are ordered).
+        {
+            const int tok = pg * MTTS_PAGE + lane;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float p = 0.f;
+                if (tok < len) {
+                    float s = bf2f(scores[((size_t)r * nq + kvh * G + g) * Lmax + tok]);
+                    p = rbf(expf(s - M[g]) / S[g]);
+                }
+                pbuf[wave][g][lane] = p;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            float e[8] = {bflo(vv[it].x), bfhi(vv[it].x), bflo(vv[it].y), bfhi(vv[it].y),
+                          bflo(vv[it].z), bfhi(vv[it].z), bflo(vv[it].w), bfhi(vv[it].w)};
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float p = pbuf[wave][g][it * 4 + sub];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[g][i] += p * e[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = acc[g][i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (sub == 0) red[wave][g][dl * 8 + i] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G * MTTS_HD; i += 256) {
+        int g = i / MTTS_HD, d = i % MTTS_HD;
+        float v = red[0][g][d] + red[1][g][d] + red[2][g][d] + red[3][g][d];
+        opart[(((size_t)r * nq + kvh * G + g) * nchunks_max + chunk) * MTTS_HD + d] = v;
+    }
+}
+
+// grid = (R, nq), block 128
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ opart, const RowMeta* __restrict__ meta,
+                                                           uint16_t* __restrict__ out_packed, int nchunks_max, int nq,
+                                                           const int32_t* __restrict__ done) {
+    if (done && *done) return;
+    const int r = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    const RowMeta m = meta[r];
+    float s = 0.f;
+    if (m.seq >= 0) {
+        const int npages = (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE;
+        const int nch = (npages + ATT_PB - 1) / ATT_PB;
+        const float* p = opart + ((size_t)r * nq + h) * nchunks_max * MTTS_HD + d;
+        for (int c = 0; c < nch; ++c) s += p[(size_t)c * MTTS_HD];
+    }
+    out_packed[xpack_off(r, h * MTTS_HD + d)] = f2bf(s);
+}
+
+template <int G>
+static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+                          const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
+                          int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale,
+                          const int32_t* done, int phase, hipStream_t st) {
+    if (phase == 0 || phase == 1) {
+        dim3 ga((pages_bound + 3) / 4, nkv, R);
+        hipLaunchKernelGGL((attn_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
+                           page_table, meta, (uint16_t*)scores, stats, max_pages, nq, nkv, scale, done);
+    }
+    if (phase == 0 || phase == 2) {
+        dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
+        hipLaunchKernelGGL((attn_pv_kernel<G>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, nchunks_max, nq, nkv, done);
+    }
+    if (phase == 0 || phase == 3)
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
+                           (uint16_t*)out_packed, nchunks_max, nq, done);
+}
+
+int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+                const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
+                int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
+                int phase, hipStream_t st) {
+    int G = nq / nkv;
+#define MTTS_ATT(GG)                                                                                              \
+    launch_attn_g<GG>(qbuf, kcache, vcache, page_table, meta, scores, stats, opart, out_packed, R, pages_bound,   \
+                      max_pages, nchunks_max, nq, nkv, scale, done, phase, st)
+    if (G == 1) MTTS_ATT(1);
+    else if (G == 2) MTTS_ATT(2);
+    else if (G == 4) MTTS_ATT(4);
+    else return -1;
+#undef MTTS_ATT
+    return 0;
+}

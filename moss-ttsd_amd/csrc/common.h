@@ -1,0 +1,63 @@
+// Shared device helpers for the mtts HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+#define MTTS_WAVE 64
+#define MTTS_MAXR 32          // rows (sequences or prefill tokens) per forward pass = one MFMA N-tile
+#define MTTS_PAGE 64          // tokens per KV page
+#define MTTS_HD 128           // head_dim the kernels are written for
+
+// bf16 bit pattern <-> fp32.  Round-to-nearest-even, NaN stays NaN, inf stays inf.
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {   // c + a.lo*b.lo + a.hi*b.hi
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Packed "fragment" layouts.  A matrix [rows32][K] that feeds
+// v_mfma_f32_32x32x16_bf16 is stored as [row_tile][k/16][lane][8] with
+// lane = (row%32) + 32*((k%16)/8), element = k%8: one wave-instruction reads one
+// contiguous KiB.  Element offset helpers (in bf16 elements):
+__host__ __device__ __forceinline__ size_t wpack_off(int n, int k, int KT) {
+    return ((((size_t)(n >> 5) * KT + (k >> 4)) * 64) + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+}
+__host__ __device__ __forceinline__ size_t xpack_off(int r, int k) {
+    return (((size_t)(k >> 4) * 64) + r + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+}
+
+// Per-row metadata of one forward pass (R <= 32 rows).
+struct RowMeta {
+    int32_t seq;     // sequence slot (page-table row), -1 = inactive row
+    int32_t pos;     // position of this token = its index among the sequence's real tokens
+    int32_t last;    // 1 if logits are wanted for this row
+    int32_t pad;
+};

@@ -1,0 +1,720 @@
+// Host side of libmtts.so: engine object, weight binding, KV page pool, the
+// prefill / decode-step orchestration and the C ABI of include/mtts.h.
+//
+// Mirrors (file:line in /root/reference):
+//   AsteroidTTSInstruct.forward inference branch   modeling_asteroid.py:337-380,411-426
+//   AsteroidTTSModel._prepare_multi_modal_inputs    modeling_asteroid.py:235-250
+//   CustomMixin._sample                             modeling_asteroid.py:83-169
+// and, third-party, transformers Qwen3Model.forward (models/qwen3/modeling_qwen3.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mtts.h"
+#include "common.h"
+
+// ---- kernels' launchers (other translation units) ---------------------------
+struct GemmPlan { int waves, ksplit, kt_per_split, kt_per_wave; };
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU = 2 };
+GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit);
+void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                 float* partial, uint16_t* out, hipStream_t st);
+void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st);
+void launch_pack_rows(const void* src, void* dst, int R, int K, hipStream_t st);
+void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st);
+void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
+                       void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st);
+void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, const void* norm_w, void* xn_packed,
+                       void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st);
+void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
+                     const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
+                     const int32_t* page_table, int max_pages, int R, int nq, int nkv, float eps, const int32_t* done,
+                     hipStream_t st);
+void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st);
+int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+                const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
+                int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
+                int phase, hipStream_t st);
+struct SeqState { int32_t nas, unfinished, kv_len, pad; };
+struct LoopState { int32_t step, done, base_length, max_length, tf_len, B, error, pad; };
+void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps,
+                   int bm_words, const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions,
+                   int32_t* err, int B, hipStream_t st);
+void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
+                          const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
+                          int32_t* decisions, int32_t* err, hipStream_t st);
+void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
+                   int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
+                   LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
+                   hipStream_t st);
+
+#define ATT_PB 8
+
+// ---- errors -------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t _e = (x);                                                               \
+        if (_e != hipSuccess) return fail(MTTS_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct Layer {
+    void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;     // packed
+    void *ln_in = nullptr, *ln_post = nullptr, *qn = nullptr, *kn = nullptr; // bf16 vectors
+    int bound = 0;
+};
+
+enum { PROF_SCORES = 0, PROF_PV = 1, PROF_GEMM = 2, PROF_STEP = 3, PROF_N = 4 };
+
+struct MttsEngine {
+    MttsConfig cfg;
+    int device = 0;
+    int H, I, L, nq, nkv, V0, Vs, Vs_pad, V0_pad, qkv_rows;
+    std::vector<Layer> layers;
+    void* emb[8] = {nullptr};          // row-major tables (gather)
+    void* head0 = nullptr;             // packed [V0_pad][H]
+    void* heads17 = nullptr;           // packed [7*Vs_pad][H]
+    void* final_norm = nullptr;
+    void *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_rows = 0;
+    int emb_bound = 0, norm_bound = 0;
+    const uint16_t** d_tables = nullptr;
+    // plans
+    GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17;
+    // workspaces
+    float* partial = nullptr;
+    void *x = nullptr, *xn = nullptr, *attn_p = nullptr, *act_p = nullptr, *qbuf = nullptr, *hlast = nullptr, *xh = nullptr;
+    void *logits0 = nullptr, *logits17 = nullptr;
+    void* scores = nullptr;
+    float *stats = nullptr, *opart = nullptr;
+    // kv
+    void *kcache = nullptr, *vcache = nullptr;
+    size_t layer_stride = 0;           // elements per layer in each cache
+    int total_pages = 0, max_pages = 0, nchunks_max = 0;
+    int32_t* d_page_table = nullptr;
+    std::vector<int32_t> h_page_table;
+    // generation state
+    SeqState* d_seqs = nullptr;
+    RowMeta* d_meta = nullptr;          // decode rows
+    LoopState* d_ls = nullptr;
+    LoopState* h_ls = nullptr;          // pinned mirror
+    int32_t *d_decisions = nullptr, *d_cur = nullptr, *d_gen = nullptr, *d_declog = nullptr, *d_forced = nullptr,
+            *d_tf = nullptr;
+    uint32_t* d_bitmaps = nullptr;
+    int bm_words = 0;
+    MttsSamplerCfg* d_scfg = nullptr;
+    int32_t* d_pf_tokens = nullptr;     // prefill staging
+    RowMeta* d_pf_meta = nullptr;
+    size_t pf_cap_rows = 0;
+    int gen_cap = 0;
+    // current run
+    int B = 0, T = 0, base_length = 0, max_length = 0, max_steps = 0, steps_issued = 0;
+    std::vector<int> n_real;
+    int max_real = 0;
+    uint64_t seed = 0;
+    bool began = false, has_forced = false;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_N];
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_bytes[PROF_N] = {0, 0, 0, 0};
+};
+
+static hipStream_t S(void* s) { return (hipStream_t)s; }
+
+const char* mtts_last_error(void) { return g_err; }
+int32_t mtts_version(void) { return 100; }
+
+template <typename T>
+static int dalloc(T** p, size_t n, bool zero = true) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    return 0;
+}
+#define TRY(x)             \
+    do {                   \
+        int _r = (x);      \
+        if (_r) return _r; \
+    } while (0)
+
+int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out) {
+    if (!c || !out) return fail(MTTS_EINVAL, "null argument");
+    if (c->head_dim != MTTS_HD) return fail(MTTS_EINVAL, "head_dim must be 128 (got %d)", c->head_dim);
+    if (c->channels != 8) return fail(MTTS_EINVAL, "channels must be 8");
+    if (c->hidden_size % 16 || c->intermediate_size % 16) return fail(MTTS_EINVAL, "hidden/intermediate must be multiples of 16");
+    if (c->num_attention_heads % c->num_key_value_heads) return fail(MTTS_EINVAL, "bad GQA ratio");
+    int G = c->num_attention_heads / c->num_key_value_heads;
+    if (G != 1 && G != 2 && G != 4) return fail(MTTS_EINVAL, "GQA group %d not built (1,2,4)", G);
+    if (c->max_batch < 1 || c->max_batch > MTTS_MAXR) return fail(MTTS_EINVAL, "max_batch must be 1..32");
+    if (c->vocab_size <= 152694 || c->speech_vocab_size <= 1024)
+        return fail(MTTS_EINVAL, "vocab too small for the reference's hard-coded mask ids 152694 / 1024");
+    HIPCHK(hipSetDevice(device));
+    MttsEngine* e = new MttsEngine();
+    e->cfg = *c;
+    e->device = device;
+    e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
+    e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
+    e->V0 = c->vocab_size; e->Vs = c->speech_vocab_size;
+    e->V0_pad = round_up(e->V0, 32); e->Vs_pad = round_up(e->Vs, 32);
+    e->qkv_rows = (e->nq + 2 * e->nkv) * MTTS_HD;
+    e->layers.resize(e->L);
+    const int H = e->H, I = e->I;
+    // packed weights (zeroed: padding rows must be zero)
+    for (auto& l : e->layers) {
+        TRY(dalloc((uint16_t**)&l.wqkv, (size_t)e->qkv_rows * H));
+        TRY(dalloc((uint16_t**)&l.wo, (size_t)H * e->nq * MTTS_HD));
+        TRY(dalloc((uint16_t**)&l.wgu, (size_t)2 * I * H));
+        TRY(dalloc((uint16_t**)&l.wd, (size_t)round_up(H, 32) * I));
+        TRY(dalloc((uint16_t**)&l.ln_in, (size_t)H));
+        TRY(dalloc((uint16_t**)&l.ln_post, (size_t)H));
+        TRY(dalloc((uint16_t**)&l.qn, (size_t)MTTS_HD));
+        TRY(dalloc((uint16_t**)&l.kn, (size_t)MTTS_HD));
+    }
+    TRY(dalloc((uint16_t**)&e->emb[0], (size_t)e->V0 * H, false));
+    for (int ch = 1; ch < 8; ++ch) TRY(dalloc((uint16_t**)&e->emb[ch], (size_t)e->Vs * H, false));
+    TRY(dalloc((uint16_t**)&e->head0, (size_t)e->V0_pad * H));
+    TRY(dalloc((uint16_t**)&e->heads17, (size_t)7 * e->Vs_pad * H));
+    TRY(dalloc((uint16_t**)&e->final_norm, (size_t)H));
+    TRY(dalloc(&e->d_tables, 8));
+    HIPCHK(hipMemcpy((void*)e->d_tables, e->emb, 8 * sizeof(void*), hipMemcpyHostToDevice));
+    // plans
+    e->p_qkv = mtts_plan_gemm(e->qkv_rows, H, 0);
+    e->p_o = mtts_plan_gemm(round_up(H, 32), e->nq * MTTS_HD, 0);
+    e->p_gu = mtts_plan_gemm(2 * I, H, 1);
+    e->p_d = mtts_plan_gemm(round_up(H, 32), I, 0);
+    e->p_h0 = mtts_plan_gemm(e->V0_pad, H, 1);
+    e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
+    size_t pmax = std::max({(size_t)e->p_qkv.ksplit * e->qkv_rows, (size_t)e->p_o.ksplit * round_up(H, 32),
+                            (size_t)e->p_d.ksplit * round_up(H, 32)});
+    TRY(dalloc(&e->partial, pmax * MTTS_MAXR));
+    TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_MAXR * H));
+    TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_MAXR * H));
+    TRY(dalloc((uint16_t**)&e->xh, (size_t)MTTS_MAXR * H));
+    TRY(dalloc((uint16_t**)&e->hlast, (size_t)MTTS_MAXR * H));
+    TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_MAXR * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_MAXR * I));
+    TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_MAXR * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_MAXR * e->V0));
+    TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
+    // KV pool
+    e->max_pages = (c->max_seq_len + MTTS_PAGE - 1) / MTTS_PAGE + 1;
+    e->total_pages = e->max_pages * c->max_batch;
+    e->nchunks_max = (e->max_pages + ATT_PB - 1) / ATT_PB;
+    e->layer_stride = (size_t)e->total_pages * e->nkv * MTTS_PAGE * MTTS_HD;
+    TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
+    TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
+    TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
+    e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
+    TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_MAXR * e->nq * e->max_pages * MTTS_PAGE));
+    TRY(dalloc(&e->stats, (size_t)MTTS_MAXR * e->nq * e->max_pages * 2));
+    TRY(dalloc(&e->opart, (size_t)MTTS_MAXR * e->nq * e->nchunks_max * MTTS_HD));
+    // state
+    TRY(dalloc(&e->d_seqs, MTTS_MAXR));
+    TRY(dalloc(&e->d_meta, MTTS_MAXR));
+    TRY(dalloc(&e->d_ls, 1));
+    HIPCHK(hipHostMalloc((void**)&e->h_ls, sizeof(LoopState)));
+    memset(e->h_ls, 0, sizeof(LoopState));
+    TRY(dalloc(&e->d_decisions, MTTS_MAXR * 8));
+    TRY(dalloc(&e->d_cur, MTTS_MAXR * 8));
+    TRY(dalloc(&e->d_tf, MTTS_MAXR * 7 * 8));
+    e->bm_words = (e->V0 + 31) / 32;
+    TRY(dalloc(&e->d_bitmaps, (size_t)MTTS_MAXR * 8 * e->bm_words));
+    TRY(dalloc(&e->d_scfg, 8));
+    *out = e;
+    return MTTS_OK;
+}
+
+int32_t mtts_engine_destroy(MttsEngine* e) {
+    if (!e) return MTTS_OK;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    for (auto& l : e->layers) {
+        hipFree(l.wqkv); hipFree(l.wo); hipFree(l.wgu); hipFree(l.wd);
+        hipFree(l.ln_in); hipFree(l.ln_post); hipFree(l.qn); hipFree(l.kn);
+    }
+    for (int c = 0; c < 8; ++c) hipFree(e->emb[c]);
+    void* ptrs[] = {e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
+                    e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->scores, e->stats,
+                    e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
+                    e->d_cur, e->d_gen, e->d_declog, e->d_forced, e->d_tf, e->d_bitmaps, e->d_scfg, e->d_pf_tokens,
+                    e->d_pf_meta};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (e->h_ls) hipHostFree(e->h_ls);
+    for (int w = 0; w < PROF_N; ++w) for (auto& pr : e->ev[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete e;
+    return MTTS_OK;
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int32_t mtts_bind_weight(MttsEngine* e, const char* name_c, const void* src, int64_t rows, int64_t cols, void* stream) {
+    if (!e || !name_c || !src) return fail(MTTS_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = S(stream);
+    std::string name(name_c);
+    const int H = e->H, I = e->I, D = MTTS_HD;
+    auto expect = [&](int64_t r, int64_t c) { return rows == r && cols == c; };
+    auto copyvec = [&](void* dst, int64_t n) -> int {
+        if (!(rows == n && cols == 1) && !(rows == 1 && cols == n)) return fail(MTTS_EINVAL, "%s: expected vector of %lld", name_c, (long long)n);
+        HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    int ch = -1;
+    if (sscanf(name_c, "model.embedding_list.%d.weight", &ch) == 1 && ends_with(name, ".weight") && name.find("embedding_list") != std::string::npos) {
+        if (ch < 0 || ch > 7) return fail(MTTS_EINVAL, "bad channel in %s", name_c);
+        int64_t V = ch == 0 ? e->V0 : e->Vs;
+        if (!expect(V, H)) return fail(MTTS_EINVAL, "%s: expected [%lld,%d] got [%lld,%lld]", name_c, (long long)V, H, (long long)rows, (long long)cols);
+        HIPCHK(hipMemcpyAsync(e->emb[ch], src, (size_t)V * H * 2, hipMemcpyDeviceToDevice, st));
+        // the head is tied to the embedding (modeling_asteroid.py:315-317)
+        if (ch == 0) launch_pack_weight(src, e->head0, V, H, e->V0_pad, 1, 0, st);
+        else launch_pack_weight(src, e->heads17, V, H, 7 * e->Vs_pad, 1, (ch - 1) * e->Vs_pad, st);
+        e->emb_bound |= 1 << ch;
+        return MTTS_OK;
+    }
+    if (name == "model.language_model.norm.weight") { TRY(copyvec(e->final_norm, H)); e->norm_bound = 1; return MTTS_OK; }
+    if (name.find("lm_heads.") == 0 || name == "model.language_model.embed_tokens.weight") return MTTS_OK;  // tied / unused
+    int n = -1;
+    char rest[128];
+    if (sscanf(name_c, "model.language_model.layers.%d.%127s", &n, rest) == 2) {
+        if (n < 0 || n >= e->L) return fail(MTTS_EINVAL, "layer index out of range in %s", name_c);
+        Layer& l = e->layers[n];
+        std::string r(rest);
+        if (r == "input_layernorm.weight") { TRY(copyvec(l.ln_in, H)); l.bound |= 1; }
+        else if (r == "post_attention_layernorm.weight") { TRY(copyvec(l.ln_post, H)); l.bound |= 2; }
+        else if (r == "self_attn.q_norm.weight") { TRY(copyvec(l.qn, D)); l.bound |= 4; }
+        else if (r == "self_attn.k_norm.weight") { TRY(copyvec(l.kn, D)); l.bound |= 8; }
+        else if (r == "self_attn.q_proj.weight") {
+            if (!expect(e->nq * D, H)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wqkv, rows, H, e->qkv_rows, 1, 0, st); l.bound |= 16;
+        } else if (r == "self_attn.k_proj.weight") {
+            if (!expect(e->nkv * D, H)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wqkv, rows, H, e->qkv_rows, 1, e->nq * D, st); l.bound |= 32;
+        } else if (r == "self_attn.v_proj.weight") {
+            if (!expect(e->nkv * D, H)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wqkv, rows, H, e->qkv_rows, 1, (e->nq + e->nkv) * D, st); l.bound |= 64;
+        } else if (r == "self_attn.o_proj.weight") {
+            if (!expect(H, e->nq * D)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wo, rows, e->nq * D, round_up(H, 32), 1, 0, st); l.bound |= 128;
+        } else if (r == "mlp.gate_proj.weight") {
+            if (!expect(I, H)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wgu, rows, H, 2 * I, 2, 0, st); l.bound |= 256;
+        } else if (r == "mlp.up_proj.weight") {
+            if (!expect(I, H)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wgu, rows, H, 2 * I, 2, 1, st); l.bound |= 512;
+        } else if (r == "mlp.down_proj.weight") {
+            if (!expect(H, I)) return fail(MTTS_EINVAL, "%s: bad shape", name_c);
+            launch_pack_weight(src, l.wd, rows, I, round_up(H, 32), 1, 0, st); l.bound |= 1024;
+        } else return fail(MTTS_EINVAL, "unknown tensor %s", name_c);
+        HIPCHK(hipGetLastError());
+        return MTTS_OK;
+    }
+    return fail(MTTS_EINVAL, "unknown tensor %s", name_c);
+}
+
+int32_t mtts_bind_rope(MttsEngine* e, const void* cosb, const void* sinb, int32_t rows, void* stream) {
+    if (!e || !cosb || !sinb || rows < 1) return fail(MTTS_EINVAL, "bad rope table");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->rope_cos) { hipFree(e->rope_cos); hipFree(e->rope_sin); }
+    TRY(dalloc((uint16_t**)&e->rope_cos, (size_t)rows * 64, false));
+    TRY(dalloc((uint16_t**)&e->rope_sin, (size_t)rows * 64, false));
+    HIPCHK(hipMemcpyAsync(e->rope_cos, cosb, (size_t)rows * 128, hipMemcpyDeviceToDevice, S(stream)));
+    HIPCHK(hipMemcpyAsync(e->rope_sin, sinb, (size_t)rows * 128, hipMemcpyDeviceToDevice, S(stream)));
+    e->rope_rows = rows;
+    return MTTS_OK;
+}
+
+int32_t mtts_weights_ready(MttsEngine* e) {
+    if (!e) return fail(MTTS_EINVAL, "null engine");
+    if (e->emb_bound != 0xff) return fail(MTTS_ESTATE, "embedding tables missing (mask %x)", e->emb_bound);
+    if (!e->norm_bound) return fail(MTTS_ESTATE, "final norm missing");
+    if (!e->rope_rows) return fail(MTTS_ESTATE, "rope table missing");
+    for (int n = 0; n < e->L; ++n)
+        if (e->layers[n].bound != 2047) return fail(MTTS_ESTATE, "layer %d incomplete (mask %x)", n, e->layers[n].bound);
+    return MTTS_OK;
+}
+
+// ---- profiling helpers ------------------------------------------------------------
+static void prof_begin(MttsEngine* e, int which, hipStream_t st, hipEvent_t* a) {
+    if (!e->prof) return;
+    hipEvent_t s0, s1;
+    hipEventCreate(&s0); hipEventCreate(&s1);
+    hipEventRecord(s0, st);
+    e->ev[which].push_back({s0, s1});
+    *a = s1;
+}
+static void prof_end(MttsEngine* e, hipStream_t st, hipEvent_t a) {
+    if (!e->prof) return;
+    hipEventRecord(a, st);
+}
+
+// ---- one forward pass over R <= 32 rows ---------------------------------------------
+// heads: 0 none, 1 from xn (rows are sequences: decode), 2 from hlast (end of prefill)
+static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d_meta, int R, int pages_bound,
+                        int heads, const int32_t* done, hipStream_t st, int64_t kv_tokens_hint) {
+    const int H = e->H, I = e->I, nq = e->nq, nkv = e->nkv;
+    const float eps = e->cfg.rms_norm_eps;
+    const float scale = 1.0f / sqrtf((float)MTTS_HD);
+    const int Hp = round_up(H, 32);
+    launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, done, st);
+    for (int n = 0; n < e->L; ++n) {
+        Layer& l = e->layers[n];
+        uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
+        uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
+        launch_gemm(EPI_PARTIAL, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
+        launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
+                        kc, vc, e->d_page_table, e->max_pages, R, nq, nkv, eps, done, st);
+        for (int phase = 1; phase <= 3; ++phase) {
+            hipEvent_t ev = nullptr;
+            if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
+            if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
+                            pages_bound, e->max_pages, e->nchunks_max, nq, nkv, scale, done, phase, st))
+                return fail(MTTS_EINVAL, "attention group size not built");
+            if (phase < 3) prof_end(e, st, ev);
+        }
+        if (e->prof) {   // algorithmic bytes: one K (or V) row of 128 bf16 per kv head per cached token
+            e->prof_bytes[PROF_SCORES] += kv_tokens_hint * nkv * MTTS_HD * 2;
+            e->prof_bytes[PROF_PV] += kv_tokens_hint * nkv * MTTS_HD * 2;
+        }
+        launch_gemm(EPI_PARTIAL, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
+        launch_resid_norm(e->partial, e->p_o.ksplit, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, done, st);
+        launch_gemm(EPI_SILU, e->p_gu, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
+        launch_gemm(EPI_PARTIAL, e->p_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
+        const bool lastl = (n == e->L - 1);
+        const void* nw = lastl ? e->final_norm : e->layers[n + 1].ln_in;
+        launch_resid_norm(e->partial, e->p_d.ksplit, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps,
+                          done, st);
+    }
+    if (heads) {
+        const void* xin = e->xn;
+        if (heads == 2) {
+            launch_pack_rows(e->hlast, e->xh, MTTS_MAXR, H, st);
+            xin = e->xh;
+        }
+        launch_gemm(EPI_BF16, e->p_h0, e->head0, xin, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, st);
+        launch_gemm(EPI_BF16, e->p_h17, e->heads17, xin, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, st);
+    }
+    HIPCHK(hipGetLastError());
+    return MTTS_OK;
+}
+
+// ---- begin: parse prompt, allocate pages, prefill --------------------------------------
+int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32_t B, int32_t T, int32_t max_length,
+                   const MttsSamplerCfg* sampler, uint64_t seed, void* stream) {
+    if (!e || !ids || !mask || !sampler) return fail(MTTS_EINVAL, "null argument");
+    TRY(mtts_weights_ready(e));
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = S(stream);
+    if (B < 1 || B > e->cfg.max_batch) return fail(MTTS_EINVAL, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    if (T < 8) return fail(MTTS_EINVAL, "T must be >= 8 (delay pattern adds 7 slots)");
+    const int base = T - 7;
+    if (max_length <= base) return fail(MTTS_EINVAL, "max_length %d leaves no room to generate (prompt slots %d)", max_length, base);
+    const int max_steps = max_length - base;
+    e->B = B; e->T = T; e->base_length = base; e->max_length = max_length; e->max_steps = max_steps;
+    e->seed = seed; e->steps_issued = 0; e->has_forced = false;
+    e->n_real.assign(B, 0);
+    e->max_real = 0;
+    // attention_mask must be the left-padded form rpadding() produces (generation_utils.py:221-237)
+    std::vector<int> pad(B, 0);
+    for (int b = 0; b < B; ++b) {
+        int p = 0;
+        while (p < base && !mask[(size_t)b * T + p]) ++p;
+        for (int t = p; t < base; ++t)
+            if (!mask[(size_t)b * T + t]) return fail(MTTS_EINVAL, "attention_mask of row %d is not left-padded", b);
+        if (p >= base) return fail(MTTS_EINVAL, "row %d has no real token in the first T-7 slots", b);
+        pad[b] = p;
+        e->n_real[b] = base - p;
+        e->max_real = std::max(e->max_real, base - p);
+    }
+    // pages
+    for (int b = 0; b < B; ++b) {
+        int need = (e->n_real[b] + max_steps + MTTS_PAGE - 1) / MTTS_PAGE;
+        if (need > e->max_pages) return fail(MTTS_ENOMEM, "row %d needs %d KV pages, pool has %d per sequence (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
+        for (int p = 0; p < e->max_pages; ++p) e->h_page_table[(size_t)b * e->max_pages + p] = b * e->max_pages + p;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_page_table, e->h_page_table.data(), e->h_page_table.size() * 4, hipMemcpyHostToDevice, st));
+    if (e->max_real + max_steps > e->rope_rows)
+        return fail(MTTS_EINVAL, "rope table has %d rows, need %d", e->rope_rows, e->max_real + max_steps);
+    // generation buffers
+    if (max_steps > e->gen_cap) {
+        if (e->d_gen) { hipFree(e->d_gen); hipFree(e->d_declog); hipFree(e->d_forced); }
+        e->gen_cap = max_steps;
+        TRY(dalloc(&e->d_gen, (size_t)max_steps * MTTS_MAXR * 8));
+        TRY(dalloc(&e->d_declog, (size_t)max_steps * MTTS_MAXR * 8));
+        TRY(dalloc(&e->d_forced, (size_t)max_steps * MTTS_MAXR * 8, false));
+    }
+    // flattened prefill rows
+    size_t Mtot = 0;
+    for (int b = 0; b < B; ++b) Mtot += e->n_real[b];
+    size_t Mpad = (Mtot + MTTS_MAXR - 1) / MTTS_MAXR * MTTS_MAXR;
+    std::vector<int32_t> toks(Mpad * 8, 0);
+    std::vector<RowMeta> metas(Mpad, RowMeta{-1, 0, 0, 0});
+    size_t r = 0;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < e->n_real[b]; ++i, ++r) {
+            const int64_t* src = ids + ((size_t)b * T + pad[b] + i) * 8;
+            for (int c = 0; c < 8; ++c) {
+                int64_t t = src[c];
+                int64_t V = c == 0 ? e->V0 : e->Vs;
+                if (t < 0 || t >= V) return fail(MTTS_EINVAL, "token %lld out of range on channel %d", (long long)t, c);
+                toks[r * 8 + c] = (int32_t)t;
+            }
+            metas[r] = RowMeta{b, i, i == e->n_real[b] - 1 ? 1 : 0, 0};
+        }
+    if (Mpad > e->pf_cap_rows) {
+        if (e->d_pf_tokens) { hipFree(e->d_pf_tokens); hipFree(e->d_pf_meta); }
+        TRY(dalloc(&e->d_pf_tokens, Mpad * 8, false));
+        TRY(dalloc(&e->d_pf_meta, Mpad, false));
+        e->pf_cap_rows = Mpad;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_pf_tokens, toks.data(), Mpad * 8 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_pf_meta, metas.data(), Mpad * sizeof(RowMeta), hipMemcpyHostToDevice, st));
+    // history bitmaps (HF repetition penalty sees the whole channel incl. pads: modeling_asteroid.py:129)
+    {
+        std::vector<uint32_t> bm((size_t)MTTS_MAXR * 8 * e->bm_words, 0u);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < base; ++t)
+                for (int c = 0; c < 8; ++c) {
+                    int64_t tk = ids[((size_t)b * T + t) * 8 + c];
+                    if (tk >= 0 && tk < (int64_t)e->bm_words * 32) bm[((size_t)b * 8 + c) * e->bm_words + (tk >> 5)] |= 1u << (tk & 31);
+                }
+        HIPCHK(hipMemcpyAsync(e->d_bitmaps, bm.data(), bm.size() * 4, hipMemcpyHostToDevice, st));
+        // teacher-forcing tail tf_inputs[:, base+s, :] for s = 0..6 (modeling_asteroid.py:143-145)
+        std::vector<int32_t> tf((size_t)MTTS_MAXR * 7 * 8, 0);
+        for (int b = 0; b < B; ++b)
+            for (int s = 0; s < 7; ++s)
+                for (int c = 0; c < 8; ++c) tf[((size_t)b * 7 + s) * 8 + c] = (int32_t)ids[((size_t)b * T + base + s) * 8 + c];
+        HIPCHK(hipMemcpyAsync(e->d_tf, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
+        std::vector<SeqState> ss(MTTS_MAXR, SeqState{-1, 0, 0, 0});
+        for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0};
+        HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
+        LoopState ls{0, 0, base, max_length, T, B, 0, 0};
+        HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
+        *e->h_ls = ls;
+        std::vector<RowMeta> dm(MTTS_MAXR, RowMeta{-1, 0, 0, 0});
+        HIPCHK(hipMemcpyAsync(e->d_meta, dm.data(), dm.size() * sizeof(RowMeta), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->d_scfg, sampler, 8 * sizeof(MttsSamplerCfg), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));   // host vectors above go out of scope
+    }
+    // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
+    const int pages_bound = (e->max_real + MTTS_PAGE - 1) / MTTS_PAGE;
+    for (size_t off = 0; off < Mpad; off += MTTS_MAXR) {
+        bool lastc = off + MTTS_MAXR >= Mpad;
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_MAXR, pages_bound, lastc ? 2 : 0, nullptr,
+                         st, 0));
+    }
+    e->began = true;
+    return MTTS_OK;
+}
+
+static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
+    for (int i = 0; i < n; ++i) {
+        if (e->steps_issued >= e->max_steps) break;
+        hipEvent_t ev = nullptr;
+        prof_begin(e, PROF_STEP, st, &ev);
+        launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
+                      e->seed, e->d_decisions, &e->d_ls->error, e->B, st);
+        launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
+                      e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, nullptr, e->cfg.eos_token_id,
+                      e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, e->max_steps, st);
+        const int len_bound = e->max_real + e->steps_issued + 1;
+        const int pages_bound = (len_bound + MTTS_PAGE - 1) / MTTS_PAGE;
+        // rough KV token count for the profile's byte figure: every row at its current length
+        int64_t kvtok = 0;
+        for (int b = 0; b < e->B; ++b) kvtok += e->n_real[b] + e->steps_issued + 1;
+        TRY(forward_rows(e, e->d_cur, e->d_meta, MTTS_MAXR, pages_bound, 1, &e->d_ls->done, st, kvtok));
+        prof_end(e, st, ev);
+        e->steps_issued++;
+    }
+    return MTTS_OK;
+}
+
+int32_t mtts_step(MttsEngine* e, int32_t n_steps, void* stream) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    HIPCHK(hipSetDevice(e->device));
+    return issue_steps(e, n_steps, S(stream));
+}
+
+int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finished, void* stream) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->h_ls, e->d_ls, sizeof(LoopState), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 2048 tokens survive top-k (set top_k <= 2048)", e->h_ls->error);
+    if (steps_done) *steps_done = e->h_ls->step;
+    if (all_finished) *all_finished = e->h_ls->done;
+    return MTTS_OK;
+}
+
+static int read_rows(MttsEngine* e, const int32_t* d_src, int64_t* host, int capacity_steps, int* n_steps) {
+    int steps = e->h_ls->step;
+    if (steps > capacity_steps) return fail(MTTS_EINVAL, "output buffer holds %d steps, need %d", capacity_steps, steps);
+    std::vector<int32_t> tmp((size_t)steps * MTTS_MAXR * 8);
+    if (steps) HIPCHK(hipMemcpy(tmp.data(), d_src, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < steps; ++s)
+        for (int b = 0; b < e->B; ++b)
+            for (int c = 0; c < 8; ++c) host[((size_t)s * e->B + b) * 8 + c] = tmp[((size_t)s * MTTS_MAXR + b) * 8 + c];
+    if (n_steps) *n_steps = steps;
+    return MTTS_OK;
+}
+
+int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_steps, int32_t* n_steps) {
+    if (!e || !e->began || !host_gen) return fail(MTTS_ESTATE, "nothing generated");
+    HIPCHK(hipSetDevice(e->device));
+    TRY(mtts_sync_state(e, nullptr, nullptr, nullptr));
+    return read_rows(e, e->d_gen, host_gen, capacity_steps, n_steps);
+}
+
+int32_t mtts_read_logits(MttsEngine* e, uint16_t* l0, uint16_t* l17, void* stream) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 2, hipMemcpyDeviceToHost));
+    if (l17) {
+        std::vector<uint16_t> tmp((size_t)MTTS_MAXR * 7 * e->Vs_pad);
+        HIPCHK(hipMemcpy(tmp.data(), e->logits17, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (int c = 0; c < 7; ++c)
+            for (int b = 0; b < e->B; ++b)
+                memcpy(l17 + ((size_t)c * e->B + b) * e->Vs, tmp.data() + ((size_t)b * 7 + c) * e->Vs_pad, (size_t)e->Vs * 2);
+    }
+    return MTTS_OK;
+}
+
+int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32_t B, int32_t T, int32_t max_length,
+                      const MttsSamplerCfg* sampler, uint64_t seed, int64_t* out, int32_t out_capacity, int32_t* out_len,
+                      const int64_t* forced, int32_t forced_len, int64_t* decisions, void* stream) {
+    if (!out || !out_len) return fail(MTTS_EINVAL, "null output");
+    TRY(mtts_begin(e, ids, mask, B, T, max_length, sampler, seed, stream));
+    hipStream_t st = S(stream);
+    const int base = e->base_length;
+    if (forced) {
+        if (!decisions) return fail(MTTS_EINVAL, "forced replay needs host_decisions");
+        std::vector<int32_t> f((size_t)e->max_steps * MTTS_MAXR * 8, -1);
+        for (int s = 0; s < e->max_steps && base + s < forced_len; ++s)
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < 8; ++c) f[((size_t)s * MTTS_MAXR + b) * 8 + c] = (int32_t)forced[((size_t)b * forced_len + base + s) * 8 + c];
+        HIPCHK(hipMemcpy(e->d_forced, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        e->has_forced = true;
+        e->max_steps = std::min(e->max_steps, forced_len - base);
+    }
+    // run ahead of the device in small batches; `done` on the device turns later steps into no-ops
+    int done = 0, steps = 0;
+    while (!done && e->steps_issued < e->max_steps) {
+        TRY(issue_steps(e, 8, st));
+        TRY(mtts_sync_state(e, &steps, &done, stream));
+    }
+    TRY(mtts_sync_state(e, &steps, &done, stream));
+    const int total = base + steps;
+    if (total > out_capacity) return fail(MTTS_EINVAL, "out_capacity %d < %d", out_capacity, total);
+    std::vector<int64_t> gen((size_t)std::max(steps, 1) * B * 8);
+    int ns = 0;
+    TRY(read_rows(e, e->d_gen, gen.data(), steps, &ns));
+    for (int b = 0; b < B; ++b) {
+        for (int t = 0; t < base; ++t)
+            for (int c = 0; c < 8; ++c) out[((size_t)b * out_capacity + t) * 8 + c] = ids[((size_t)b * T + t) * 8 + c];
+        for (int s = 0; s < steps; ++s)
+            for (int c = 0; c < 8; ++c) out[((size_t)b * out_capacity + base + s) * 8 + c] = gen[((size_t)s * B + b) * 8 + c];
+    }
+    if (decisions) TRY(read_rows(e, e->d_declog, decisions, steps, &ns));
+    *out_len = total;
+    return MTTS_OK;
+}
+
+int32_t mtts_profile_enable(MttsEngine* e, int32_t on) {
+    if (!e) return fail(MTTS_EINVAL, "null engine");
+    e->prof = on != 0;
+    for (int w = 0; w < PROF_N; ++w) {
+        for (auto& pr : e->ev[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        e->ev[w].clear();
+        e->prof_bytes[w] = 0;
+    }
+    return MTTS_OK;
+}
+
+int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_t* launches, int64_t* bytes) {
+    if (!e || which < 0 || which >= PROF_N) return fail(MTTS_EINVAL, "bad profile slot");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    double tot = 0;
+    for (auto& pr : e->ev[which]) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)e->ev[which].size();
+    if (bytes) *bytes = e->prof_bytes[which];
+    return MTTS_OK;
+}
+
+// ---- per-kernel entry points --------------------------------------------------------
+int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream) {
+    if (!w || !x || !y || M < 1 || M > MTTS_MAXR || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=32, K%%16==0");
+    hipStream_t st = S(stream);
+    int Npad = round_up(N, 32);
+    void *wp = nullptr, *xp = nullptr;
+    float* part = nullptr;
+    GemmPlan p = mtts_plan_gemm(Npad, K, ksplit);
+    TRY(dalloc((uint16_t**)&wp, (size_t)Npad * K));
+    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_MAXR * K));
+    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_MAXR * Npad));
+    launch_pack_weight(w, wp, N, K, Npad, 1, 0, st);
+    launch_pack_rows(x, xp, M, K, st);
+    launch_gemm(EPI_PARTIAL, p, wp, xp, K, Npad, Npad, part, nullptr, st);
+    launch_reduce_partial_bf16(part, y, p.ksplit, Npad, N, M, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(wp); hipFree(xp); hipFree(part);
+    return MTTS_OK;
+}
+
+int32_t mtts_k_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t n, float eps, void* stream) {
+    if (!x || !w || !y || rows < 1 || n < 1) return fail(MTTS_EINVAL, "rmsnorm: bad argument");
+    launch_rmsnorm_rows(x, w, y, rows, n, eps, S(stream));
+    HIPCHK(hipGetLastError());
+    return MTTS_OK;
+}
+
+int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const void* bitmap, const MttsSamplerCfg* cfg,
+                      int32_t mask_id, uint64_t seed, int32_t step, int32_t channel, int32_t* dev_tokens, void* stream) {
+    if (!logits || !cfg || !dev_tokens || rows < 1 || vocab < 1 || channel < 0 || channel > 7) return fail(MTTS_EINVAL, "sample: bad argument");
+    hipStream_t st = S(stream);
+    MttsSamplerCfg h[8];
+    for (int i = 0; i < 8; ++i) h[i] = *cfg;
+    MttsSamplerCfg* d = nullptr;
+    int32_t *err = nullptr, *dec = nullptr;
+    TRY(dalloc(&d, 8));
+    TRY(dalloc(&err, 1));
+    TRY(dalloc(&dec, (size_t)rows * 8));
+    HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+    launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int32_t> hd((size_t)rows * 8);
+    int32_t herr = 0;
+    HIPCHK(hipMemcpy(hd.data(), dec, hd.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> outv(rows);
+    for (int r = 0; r < rows; ++r) outv[r] = hd[(size_t)r * 8 + channel];
+    HIPCHK(hipMemcpy(dev_tokens, outv.data(), rows * 4, hipMemcpyHostToDevice));
+    hipFree(d); hipFree(err); hipFree(dec);
+    if (herr) return fail(MTTS_EINVAL, "sample: more than 2048 tokens survive top-k");
+    return MTTS_OK;
+}

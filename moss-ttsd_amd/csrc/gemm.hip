@@ -1,0 +1,205 @@
+// Skinny bf16 GEMM for the decode step: Y[32 rows, N] = X[32, K] * W[N, K]^T.
+//
+// Replaces every nn.Linear on the decode path (q/k/v/o_proj, gate/up/down_proj:
+// transformers modeling_qwen3.py:81-83,223-238; the 8 tied lm_heads: reference
+// modeling_asteroid.py:412).  The weight is streamed exactly once per call and
+// is the only HBM traffic that matters (X is 128 KiB and lives in L2).
+//
+// Layout: W and X are stored in MFMA-fragment order (common.h wpack_off /
+// xpack_off) so that every wave-instruction is one contiguous KiB.  One block
+// owns one 32-row N-tile; its waves split the K range and reduce through LDS.
+// With v_mfma_f32_32x32x16_bf16, A = W tile (32 n x 16 k), B = X^T (16 k x 32
+// rows): D[n][row], lane holds column `row = lane&31` and 16 n values.
+#include "common.h"
+
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU = 2 };
+
+// grid = (N/32, ksplit); block = WAVES*64.
+// kt_per_split: k-tiles (of 16) per blockIdx.y; kt_per_wave: per wave inside that.
+template <int WAVES, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
+    const u32x4_t* __restrict__ Wp, const u32x4_t* __restrict__ Xp, int KT, int kt_per_split,
+    int kt_per_wave, float* __restrict__ partial, uint16_t* __restrict__ out, int Npad, int n_valid) {
+    __shared__ float red[WAVES][16][64];
+    const int nt = blockIdx.x, ks = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int kt0 = ks * kt_per_split + wave * kt_per_wave;
+    int kt1 = min(min(kt0 + kt_per_wave, (ks + 1) * kt_per_split), KT);
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const u32x4_t* wp = Wp + ((size_t)nt * KT + kt0) * 64 + lane;
+    const u32x4_t* xp = Xp + (size_t)kt0 * 64 + lane;
+    int n = kt1 - kt0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        u32x4_t a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = xp[(size_t)(i + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a[u], *(bf16x8_t*)&b[u], acc, 0, 0, 0);
+    }
+    for (; i < n; ++i) {
+        u32x4_t a = __builtin_nontemporal_load(wp + (size_t)i * 64);
+        u32x4_t b = xp[(size_t)i * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a, *(bf16x8_t*)&b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const int l2 = threadIdx.x & 63;
+    for (int q = threadIdx.x >> 6; q < 4; q += WAVES) {      // q: register quad 4q..4q+3
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = red[0][4 * q + j][l2];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[w][4 * q + j][l2];
+        v[j] = s;
+    }
+    const int row = l2 & 31;                       // activation row (sequence / token)
+    const int nl = 8 * q + 4 * (l2 >> 5);          // first of 4 consecutive n in the tile
+    const int n0 = nt * 32 + nl;
+    if (EPI == EPI_PARTIAL) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(partial + ((size_t)ks * MTTS_MAXR + row) * Npad + n0) = o;
+    } else if (EPI == EPI_BF16) {
+        // row-major [32][n_valid] bf16 (logits): rows are not 8-byte aligned when n_valid is odd
+        uint16_t* o = out + (size_t)row * n_valid + n0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+    } else {
+        // rows interleaved gate,up,gate,up: SwiGLU (modeling_qwen3.py:81-83) with the
+        // reference's bf16 rounding points: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
+        // Output goes straight into the X-fragment layout of the down projection.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float g = rbf(v[2 * j]), u = rbf(v[2 * j + 1]);
+            float a = rbf(g / (1.0f + expf(-g)));
+            int idx = (n0 >> 1) + j;
+            out[xpack_off(row, idx)] = f2bf(a * u);
+        }
+    }
+    }
+}
+
+// Pack a row-major bf16 matrix [rows][cols] into fragment order inside a packed
+// buffer of rows_pad rows (pre-zeroed by the caller).  Source row s lands on packed row
+// s*row_mul + row_off: (1,off) places q/k/v or the 7 speech heads one after another,
+// (2,0)/(2,1) interleaves gate and up rows for the fused SwiGLU epilogue.
+__global__ void pack_weight_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                   int rows, int cols, int rows_pad, int row_mul, int row_off) {
+    const int KT = cols >> 4;
+    size_t total = (size_t)rows_pad * cols / 8;          // 16-byte groups
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        // g indexes the packed array in units of 8 elements: [nt][kt][lane]
+        int lane = (int)(g & 63);
+        size_t t = g >> 6;
+        int kt = (int)(t % KT);
+        int nt = (int)(t / KT);
+        int p = nt * 32 + (lane & 31) - row_off;
+        int k = kt * 16 + 8 * (lane >> 5);
+        if (p < 0 || (p % row_mul) != 0) continue;
+        int srow = p / row_mul;
+        if (srow >= rows) continue;
+        *(u32x4_t*)(dst + g * 8) = *(const u32x4_t*)(src + (size_t)srow * cols + k);
+    }
+}
+
+// Row-major activations [R][K] bf16 -> X-fragment layout (rows >= R are zero).
+__global__ void pack_rows_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int R, int K) {
+    int total = (K >> 4) * 64;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        int lane = g & 63, kt = g >> 6;
+        int r = lane & 31, k = kt * 16 + 8 * (lane >> 5);
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (r < R) v = *(const u32x4_t*)(src + (size_t)r * K + k);
+        *(u32x4_t*)(dst + (size_t)g * 8) = v;
+    }
+}
+
+// Sum split-K partials and round to bf16, row-major output (unit-test epilogue).
+__global__ void reduce_partial_bf16_kernel(const float* __restrict__ partial, uint16_t* __restrict__ out,
+                                           int ksplit, int Npad, int n_valid, int R) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * n_valid) return;
+    int r = idx / n_valid, n = idx % n_valid;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += partial[((size_t)k * MTTS_MAXR + r) * Npad + n];
+    out[idx] = f2bf(s);
+}
+
+struct GemmPlan {
+    int waves, ksplit, kt_per_split, kt_per_wave;
+};
+
+// Choose the decomposition so that the grid is >= ~256 blocks where the shape allows
+// and every wave gets >= 4 k-tiles.
+static GemmPlan plan_gemm(int Npad, int K, int want_ksplit) {
+    GemmPlan p;
+    int KT = K / 16, ntiles = Npad / 32;
+    int ks = want_ksplit;
+    if (ks <= 0) {
+        ks = 1;
+        while (ntiles * ks < 256 && ks < 8 && KT / (ks * 2) >= 16) ks *= 2;
+    }
+    p.ksplit = ks;
+    p.kt_per_split = (KT + ks - 1) / ks;
+    int w = 8;
+    while (w > 1 && p.kt_per_split / w < 4) w >>= 1;
+    if (ntiles * ks >= 2048 && w > 4) w = 4;
+    p.waves = w;
+    p.kt_per_wave = (p.kt_per_split + w - 1) / w;
+    return p;
+}
+
+template <int EPI>
+static void launch_gemm_epi(const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                            float* partial, uint16_t* out, hipStream_t st) {
+    dim3 grid(Npad / 32, p.ksplit);
+    int KT = K / 16;
+#define MTTS_GEMM_CASE(WV)                                                                            \
+    case WV:                                                                                          \
+        hipLaunchKernelGGL((gemm_skinny_kernel<WV, EPI>), grid, dim3(WV * 64), 0, st,                 \
+                           (const u32x4_t*)Wp, (const u32x4_t*)Xp, KT, p.kt_per_split, p.kt_per_wave, \
+                           partial, out, Npad, n_valid);                                              \
+        break;
+    switch (p.waves) {
+        MTTS_GEMM_CASE(8)
+        MTTS_GEMM_CASE(4)
+        MTTS_GEMM_CASE(2)
+        MTTS_GEMM_CASE(1)
+    }
+#undef MTTS_GEMM_CASE
+}
+
+void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                 float* partial, uint16_t* out, hipStream_t st) {
+    if (epi == EPI_PARTIAL) launch_gemm_epi<EPI_PARTIAL>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else if (epi == EPI_BF16) launch_gemm_epi<EPI_BF16>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else launch_gemm_epi<EPI_SILU>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+}
+
+GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit) { return plan_gemm(Npad, K, want_ksplit); }
+
+void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st) {
+    size_t total = (size_t)rows_pad * cols / 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, rows,
+                       cols, rows_pad, row_mul, row_off);
+}
+void launch_pack_rows(const void* src, void* dst, int R, int K, hipStream_t st) {
+    int total = (K / 16) * 64;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint16_t*)src,
+                       (uint16_t*)dst, R, K);
+}
+void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st) {
+    int total = R * n_valid;
+    hipLaunchKernelGGL(reduce_partial_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial,
+                       (uint16_t*)out, ksplit, Npad, n_valid, R);
+}

@@ -1,0 +1,189 @@
+// Elementwise / normalisation kernels of one decoder layer, each fused with the
+// split-K reduction of the GEMM in front of it.  All rounding points follow the
+// reference's CPU bf16 execution (oracle/asteroid_oracle.py lists them).
+#include "common.h"
+
+// block-wide sum over 256 threads
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// K1 + first RMSNorm.  reference modeling_asteroid.py:244-248: zeros, then
+// `+= Emb_c(ids[...,c])` for c = 0..7 in the weight dtype (8 bf16 roundings),
+// followed by layer 0's input_layernorm (modeling_qwen3.py:59-64).
+// grid = R rows, block 256.  Writes the residual stream x[R][H] (bf16) and the
+// normalised activations in X-fragment layout.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_norm_kernel(
+    const int32_t* __restrict__ tokens /*[R][8]*/, const RowMeta* __restrict__ meta,
+    const uint16_t* const* __restrict__ tables /*[8]*/, const uint16_t* __restrict__ norm_w,
+    uint16_t* __restrict__ x, uint16_t* __restrict__ xn_packed, int H, float eps, const int32_t* __restrict__ done) {
+    __shared__ float sh[4];
+    if (done && *done) return;
+    const int r = blockIdx.x;
+    const bool active = meta[r].seq >= 0;
+    float ss = 0.f;
+    // each thread owns elements i = threadIdx.x + 256*j
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float acc = 0.f;
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                int t = tokens[r * 8 + c];
+                acc = rbf(acc + bf2f(tables[c][(size_t)t * H + i]));
+            }
+        }
+        x[(size_t)r * H + i] = f2bf(acc);
+        ss += acc * acc;
+    }
+    float tot = block_sum_256(ss, sh);
+    float inv = 1.0f / sqrtf(tot / (float)H + eps);
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = bf2f(x[(size_t)r * H + i]);
+        float y = rbf(bf2f(norm_w[i]) * rbf(v * inv));
+        xn_packed[xpack_off(r, i)] = f2bf(y);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [split-K reduce] + residual add + RMSNorm (modeling_qwen3.py:299-324, :59-64).
+//   y = bf16(sum_ks partial)            (the Linear's bf16 output)
+//   x = bf16(x + y)                     (residual, bf16 add)
+//   xn = bf16(w * bf16(x * rsqrt(mean(x^2)+eps)))
+// xn goes to the X-fragment layout for the next GEMM; rows flagged `last` also
+// store xn row-major into hlast[seq] (final norm -> LM heads).
+// grid = R, block 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resid_norm_kernel(
+    const float* __restrict__ partial, int ksplit, int Npad, uint16_t* __restrict__ x,
+    const uint16_t* __restrict__ norm_w, uint16_t* __restrict__ xn_packed, uint16_t* __restrict__ hlast,
+    const RowMeta* __restrict__ meta, int H, float eps, const int32_t* __restrict__ done) {
+    __shared__ float sh[4];
+    if (done && *done) return;
+    const int r = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float s = partial[(size_t)r * Npad + i];
+        for (int k = 1; k < ksplit; ++k) s += partial[((size_t)k * MTTS_MAXR + r) * Npad + i];
+        float v = rbf(bf2f(x[(size_t)r * H + i]) + rbf(s));
+        x[(size_t)r * H + i] = f2bf(v);
+        ss += v * v;
+    }
+    float tot = block_sum_256(ss, sh);
+    float inv = 1.0f / sqrtf(tot / (float)H + eps);
+    const RowMeta m = meta[r];
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = bf2f(x[(size_t)r * H + i]);
+        uint16_t y = f2bf(bf2f(norm_w[i]) * rbf(v * inv));
+        if (xn_packed) xn_packed[xpack_off(r, i)] = y;
+        if (hlast && m.seq >= 0 && m.last) hlast[(size_t)m.seq * H + i] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// QKV epilogue: split-K reduce -> bf16; per-head q/k RMSNorm (modeling_qwen3.py
+// :251-252); RoPE in bf16 with three roundings (:148-170); q to qbuf, k/v into
+// the paged cache (replaces DynamicCache.update's torch.cat, :258-259).
+//   K page layout: [page][kvh][d/8][token 0..63][8]   (token-major inner: the
+//   score kernel reads one token per lane with no cross-lane reduction)
+//   V page layout: [page][kvh][token 0..63][128]
+// grid = (R, nq + 2*nkv), block 64 (lane l owns d = l and d = l+64).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void qkv_post_kernel(
+    const float* __restrict__ partial, int ksplit, int Npad, const RowMeta* __restrict__ meta,
+    const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
+    const uint16_t* __restrict__ rope_cos, const uint16_t* __restrict__ rope_sin,
+    uint16_t* __restrict__ qbuf /*[R][nq][128]*/, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
+    const int32_t* __restrict__ page_table, int max_pages, int nq, int nkv, float eps,
+    const int32_t* __restrict__ done) {
+    if (done && *done) return;
+    const int r = blockIdx.x, h = blockIdx.y, l = threadIdx.x;
+    const RowMeta m = meta[r];
+    if (m.seq < 0) return;
+    const int col = h * MTTS_HD;
+    float a = partial[(size_t)r * Npad + col + l];
+    float b = partial[(size_t)r * Npad + col + l + 64];
+    for (int k = 1; k < ksplit; ++k) {
+        a += partial[((size_t)k * MTTS_MAXR + r) * Npad + col + l];
+        b += partial[((size_t)k * MTTS_MAXR + r) * Npad + col + l + 64];
+    }
+    a = rbf(a);
+    b = rbf(b);
+    const int page = page_table[(size_t)m.seq * max_pages + (m.pos >> 6)];
+    const int tok = m.pos & 63;
+    if (h >= nq + nkv) {   // V head: no norm, no rope
+        const int kvh = h - nq - nkv;
+        uint16_t* dst = vcache + (((size_t)page * nkv + kvh) * MTTS_PAGE + tok) * MTTS_HD;
+        dst[l] = f2bf(a);
+        dst[l + 64] = f2bf(b);
+        return;
+    }
+    const uint16_t* nw = (h < nq) ? qnorm_w : knorm_w;
+    float ss = wave_sum(a * a + b * b);
+    float inv = 1.0f / sqrtf(ss / (float)MTTS_HD + eps);
+    a = rbf(bf2f(nw[l]) * rbf(a * inv));
+    b = rbf(bf2f(nw[l + 64]) * rbf(b * inv));
+    const float c = bf2f(rope_cos[(size_t)m.pos * 64 + l]);
+    const float s = bf2f(rope_sin[(size_t)m.pos * 64 + l]);
+    // q_embed = q*cos + rotate_half(q)*sin ; rotate_half = cat(-x2, x1)
+    float o1 = rbf(rbf(a * c) + rbf(-b * s));
+    float o2 = rbf(rbf(b * c) + rbf(a * s));
+    if (h < nq) {
+        uint16_t* dst = qbuf + ((size_t)r * nq + h) * MTTS_HD;
+        dst[l] = f2bf(o1);
+        dst[l + 64] = f2bf(o2);
+    } else {
+        const int kvh = h - nq;
+        uint16_t* base = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD);
+        // element (tok, d) at ((d/8)*64 + tok)*8 + d%8
+        base[(((l >> 3) * 64) + tok) * 8 + (l & 7)] = f2bf(o1);
+        base[((((l + 64) >> 3) * 64) + tok) * 8 + (l & 7)] = f2bf(o2);
+    }
+}
+
+// Standalone RMSNorm over rows (unit-test entry point mtts_k_rmsnorm).
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                           uint16_t* __restrict__ y, int n, float eps) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = bf2f(x[(size_t)r * n + i]);
+        ss += v * v;
+    }
+    float tot = block_sum_256(ss, sh);
+    float inv = 1.0f / sqrtf(tot / (float)n + eps);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = bf2f(x[(size_t)r * n + i]);
+        y[(size_t)r * n + i] = f2bf(bf2f(w[i]) * rbf(v * inv));
+    }
+}
+
+void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
+                       void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st) {
+    hipLaunchKernelGGL(embed_norm_kernel, dim3(R), dim3(256), 0, st, tokens, meta, tables, (const uint16_t*)norm_w,
+                       (uint16_t*)x, (uint16_t*)xn_packed, H, eps, done);
+}
+void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, const void* norm_w, void* xn_packed,
+                       void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st) {
+    hipLaunchKernelGGL(resid_norm_kernel, dim3(R), dim3(256), 0, st, partial, ksplit, Npad, (uint16_t*)x,
+                       (const uint16_t*)norm_w, (uint16_t*)xn_packed, (uint16_t*)hlast, meta, H, eps, done);
+}
+void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
+                     const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
+                     const int32_t* page_table, int max_pages, int R, int nq, int nkv, float eps, const int32_t* done,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(R, nq + 2 * nkv), dim3(64), 0, st, partial, ksplit, Npad, meta,
+                       (const uint16_t*)qnw, (const uint16_t*)knw, (const uint16_t*)cosb, (const uint16_t*)sinb,
+                       (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, nq, nkv, eps, done);
+}
+void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w,
+                       (uint16_t*)y, n, eps);
+}

@@ -1,0 +1,80 @@
+"""ctypes binding of libmtts.so (include/mtts.h).  Fails loudly when the HIP
+library is missing: there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmtts.so")
+
+
+class MttsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+        "num_key_value_heads", "head_dim", "channels", "speech_vocab_size", "speech_pad_token",
+        "speech_range_lo", "speech_range_hi", "eos_token_id", "max_position")] + [
+        ("rms_norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_seq_len", C.c_int32)]
+
+
+class MttsSamplerCfg(C.Structure):
+    _fields_ = [("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_float),
+                ("one_minus_top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float)]
+
+
+class MttsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "mtts_last_error": (C.c_char_p, []),
+    "mtts_version": (C.c_int32, []),
+    "mtts_engine_create": (C.c_int32, [C.POINTER(MttsConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "mtts_engine_destroy": (C.c_int32, [C.c_void_p]),
+    "mtts_bind_weight": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "mtts_bind_rope": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mtts_weights_ready": (C.c_int32, [C.c_void_p]),
+    "mtts_generate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(MttsSamplerCfg), C.c_uint64, C.c_void_p, C.c_int32,
+                                  C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_begin": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                               C.POINTER(MttsSamplerCfg), C.c_uint64, C.c_void_p]),
+    "mtts_step": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mtts_sync_state": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    "mtts_read_generated": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "mtts_read_logits": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mtts_profile_read": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64)]),
+    "mtts_k_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p]),
+    "mtts_k_rmsnorm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "mtts_k_sample": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(MttsSamplerCfg),
+                                  C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MttsError(f"{LIB_PATH} is missing: build it with `python moss-ttsd_amd/build.py` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MttsError(f"libmtts error {rc}: {lib().mtts_last_error().decode()}")

@@ -1,0 +1,156 @@
+"""Python handle on the HIP engine: device memory and streams come from
+PyTorch-ROCm, everything that computes lives in libmtts.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def sampler_cfgs(layers=None, do_samples=None):
+    """generation_config.layers / do_samples (reference modeling_asteroid.py:95-106) -> MttsSamplerCfg[8]."""
+    arr = (capi.MttsSamplerCfg * 8)()
+    for i in range(8):
+        lc = (layers[i] if layers and i < len(layers) else {}) or {}
+        s = arr[i]
+        s.do_sample = 1 if (do_samples and do_samples[i]) else 0
+        s.top_k = int(lc.get("top_k") or 0)
+        tp = lc.get("top_p")
+        s.top_p = float(tp) if tp is not None else 0.0
+        s.one_minus_top_p = float(np.float32(1.0 - tp)) if tp is not None else 0.0
+        t = lc.get("temperature")
+        s.temperature = float(t) if t is not None else 0.0
+        rp = lc.get("repetition_penalty")
+        s.repetition_penalty = float(rp) if rp is not None else 0.0
+    return arr
+
+
+def rope_tables(head_dim, theta, rows, device):
+    """cos/sin exactly as Qwen3RotaryEmbedding.forward builds them (transformers
+    modeling_qwen3.py:96-138): fp32 inv_freq, fp32 outer product, cos/sin, cast to bf16."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    pos = torch.arange(rows, dtype=torch.float)
+    freqs = (inv_freq[:, None] @ pos[None, :]).transpose(0, 1)            # [rows, 64]
+    return (freqs.cos().to(torch.bfloat16).contiguous().to(device),
+            freqs.sin().to(torch.bfloat16).contiguous().to(device))
+
+
+class Engine:
+    def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise capi.MttsError("no GPU visible: the mtts engine only runs on MI355X (no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = capi.lib()
+        c = capi.MttsConfig()
+        for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                  "num_key_value_heads", "head_dim", "channels", "speech_vocab_size", "speech_pad_token",
+                  "eos_token_id"):
+            setattr(c, k, int(cfg[k]))
+        c.speech_range_lo, c.speech_range_hi = int(cfg["speech_token_range"][0]), int(cfg["speech_token_range"][1])
+        c.max_position = int(max_seq_len) + 8
+        c.rms_norm_eps = float(cfg["rms_norm_eps"])
+        c.max_batch, c.max_seq_len = int(max_batch), int(max_seq_len)
+        self._h = C.c_void_p()
+        capi.check(self.lib.mtts_engine_create(C.byref(c), self.device.index or 0, C.byref(self._h)))
+        cos, sin = rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position, self.device)
+        torch.cuda.synchronize(self.device)
+        capi.check(self.lib.mtts_bind_rope(self._h, cos.data_ptr(), sin.data_ptr(), c.max_position, None))
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if self._h:
+            self.lib.mtts_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------
+    def bind(self, name: str, tensor: torch.Tensor):
+        t = tensor.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        rows, cols = (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.shape[0], 1)
+        capi.check(self.lib.mtts_bind_weight(self._h, name.encode(), t.data_ptr(), rows, cols, None))
+        torch.cuda.synchronize(self.device)     # the engine has packed its own copy; `t` may go
+
+    def bind_state_dict(self, sd):
+        for k, v in sd.items():
+            if k.startswith("lm_heads.") or k.endswith("embed_tokens.weight"):
+                continue
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(v)
+            self.bind(k, v)
+        capi.check(self.lib.mtts_weights_ready(self._h))
+
+    # ---- generation --------------------------------------------------------
+    @staticmethod
+    def _host_inputs(input_ids, attention_mask):
+        ids = np.ascontiguousarray(np.asarray(input_ids.cpu() if torch.is_tensor(input_ids) else input_ids), dtype=np.int64)
+        m = attention_mask.cpu().numpy() if torch.is_tensor(attention_mask) else np.asarray(attention_mask)
+        m = np.ascontiguousarray((m > 0).astype(np.uint8))
+        assert ids.ndim == 3 and ids.shape[2] == 8 and m.shape == ids.shape[:2]
+        return ids, m
+
+    def generate(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0, forced=None):
+        ids, m = self._host_inputs(input_ids, attention_mask)
+        B, T, _ = ids.shape
+        cap = int(max_length)
+        out = np.zeros((B, cap, 8), dtype=np.int64)
+        out_len = C.c_int32(0)
+        scfg = sampler_cfgs(layers, do_samples)
+        fptr, flen, dptr, dec = None, 0, None, None
+        if forced is not None:
+            forced = np.ascontiguousarray(forced, dtype=np.int64)
+            flen = forced.shape[1]
+            fptr = forced.ctypes.data
+            dec = np.zeros((cap, B, 8), dtype=np.int64)
+            dptr = dec.ctypes.data
+        capi.check(self.lib.mtts_generate(self._h, ids.ctypes.data, m.ctypes.data, B, T, int(max_length), scfg,
+                                          C.c_uint64(seed), out.ctypes.data, cap, C.byref(out_len), fptr, flen, dptr, None))
+        res = out[:, :out_len.value].copy()
+        if forced is not None:
+            return res, dec[:out_len.value - (T - 7)].copy()
+        return res
+
+    def begin(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0):
+        ids, m = self._host_inputs(input_ids, attention_mask)
+        B, T, _ = ids.shape
+        self._B, self._T = B, T
+        capi.check(self.lib.mtts_begin(self._h, ids.ctypes.data, m.ctypes.data, B, T, int(max_length),
+                                       sampler_cfgs(layers, do_samples), C.c_uint64(seed), None))
+
+    def step(self, n=1):
+        capi.check(self.lib.mtts_step(self._h, int(n), None))
+
+    def sync_state(self):
+        s, d = C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.mtts_sync_state(self._h, C.byref(s), C.byref(d), None))
+        return s.value, bool(d.value)
+
+    def read_generated(self, capacity_steps):
+        buf = np.zeros((capacity_steps, self._B, 8), dtype=np.int64)
+        n = C.c_int32(0)
+        capi.check(self.lib.mtts_read_generated(self._h, buf.ctypes.data, capacity_steps, C.byref(n)))
+        return buf[:n.value]
+
+    def read_logits(self):
+        V0, Vs = self.cfg["vocab_size"], self.cfg["speech_vocab_size"]
+        l0 = np.zeros((self._B, V0), dtype=np.uint16)
+        l17 = np.zeros((7, self._B, Vs), dtype=np.uint16)
+        capi.check(self.lib.mtts_read_logits(self._h, l0.ctypes.data, l17.ctypes.data, None))
+        f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
+        return f(l0), f(l17)
+
+    def profile(self, on=True):
+        capi.check(self.lib.mtts_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, which):
+        ms, n, by = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        capi.check(self.lib.mtts_profile_read(self._h, which, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
