@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- audio codec tokens/s of the MI355X-native AR decode path.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): batch 32
+synthetic dialogues per GPU, ASSUMED Qwen3-1.7B-class AsteroidTTS dims (SURVEY.md
+reading notes), bf16, top-k/top-p sampling on all 8 channels, KV context ramped
+to 4096 tokens per sequence; the timed region is K decode steps at that context
+(the hardest point of the ramp), inputs (weights, KV pages) resident in HBM.
+A "step" = one decode step of the whole batch = B frames = 8*B codec ids.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL), dialogues are
+independent, so the batch is sharded (32 per rank, weak scaling); the only
+collectives are the weight broadcast at start-up and the metric reduction.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "moss-ttsd_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_step(cfg, B, L):
+    """W + B*L*kv_bytes + B*(kv_bytes + 8*H*2)."""
+    H, I, nl = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    nq, nkv, D = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    per_layer = H * (nq + 2 * nkv) * D + nq * D * H + 3 * H * I + 2 * H + 2 * D
+    W = 2 * (nl * per_layer + H + cfg["vocab_size"] * H + 7 * cfg["speech_vocab_size"] * H)
+    kv = 2 * nl * nkv * D * 2
+    return W + B * L * kv + B * (kv + 8 * H * 2), W, kv
+
+
+def make_weights_on_device(cfg, seed, device, rank, world):
+    """Random-init weights of the architecture, generated on rank 0's GPU and broadcast
+    over RCCL -- yields (name, tensor) one at a time to bound memory."""
+    import torch
+    import torch.distributed as dist
+    from mtts import synth
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lo, hi = cfg["speech_token_range"]
+    for name, shape, kind in synth.weight_shapes(cfg):
+        t = torch.empty(shape, dtype=torch.bfloat16, device=device)
+        if rank == 0:
+            if kind == "norm":
+                t.copy_(1.0 + 0.1 * torch.randn(shape, device=device, generator=g))
+            else:
+                t.copy_(0.02 * torch.randn(shape, device=device, generator=g))
+                if name.endswith("embedding_list.0.weight"):
+                    # keep channel 0 inside the speech range so no dialogue flushes early
+                    t[lo:hi] *= 8.0
+        if world > 1:
+            dist.broadcast(t, src=0)
+        yield name, t
+
+
+def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
+    """The oracle (numpy restatement of the reference's eager CPU path) timed on this
+    box's host cores on a bounded sample: `layers_sampled` of the decoder layers at
+    full width + all 8 heads, batch B at KV length L, `steps` decode steps; the
+    per-layer time is scaled to the full depth."""
+    from oracle import asteroid_oracle as ao
+    from mtts import synth
+    small = dict(cfg)
+    small["num_hidden_layers"] = layers_sampled
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape, kind in synth.weight_shapes(small):
+        if kind == "norm":
+            w[name] = np.ones(shape, dtype=np.float32)
+        else:
+            a = rng.standard_normal(shape, dtype=np.float32)
+            a *= np.float32(0.02)
+            w[name] = ao.round_bf16(a)
+    orc = ao.AsteroidOracle(small, w, "bf16")
+    nkv, D = cfg["num_key_value_heads"], cfg["head_dim"]
+    for n in range(layers_sampled):
+        orc.K[n] = ao.round_bf16(rng.standard_normal((B, nkv, L - steps, D), dtype=np.float32))
+        orc.V[n] = ao.round_bf16(rng.standard_normal((B, nkv, L - steps, D), dtype=np.float32))
+    ids = np.stack([rng.integers(0, 1024, (B, 1)) for _ in range(8)], axis=-1)
+    ids[..., 0] += 151665
+    mask = np.ones((B, L), dtype=np.int64)
+    t_layers, t_heads = [], []
+    for s in range(steps):
+        pos = np.full((B, 1), L - steps + s, dtype=np.int64)
+        t0 = time.perf_counter()
+        x = orc.forward_hidden(ids, pos, mask[:, :L - steps + s + 1])
+        t1 = time.perf_counter()
+        orc.heads(x)
+        t2 = time.perf_counter()
+        t_layers.append(t1 - t0)
+        t_heads.append(t2 - t1)
+    per_layer = min(t_layers) / layers_sampled
+    step_time = per_layer * cfg["num_hidden_layers"] + min(t_heads)
+    return step_time, per_layer, min(t_heads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32, help="dialogues per GPU")
+    ap.add_argument("--context", type=int, default=4096)
+    ap.add_argument("--prompt", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=0, help="override depth (debug only; result is marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mtts import synth
+    from mtts.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    cfg = synth.assumed_1p7b()
+    if args.layers:
+        cfg["num_hidden_layers"] = args.layers
+    B, K, W, L = args.batch, args.steps, args.warmup, args.context
+    T = args.prompt
+    n_real = T - 7
+    ramp = L - n_real - (K + W) - args.profile_steps
+    assert ramp >= 0, "context too small for prompt + steps"
+
+    t_setup = time.perf_counter()
+    eng = Engine(cfg, max_batch=B, max_seq_len=L + 64, device=str(device))
+    for name, t in make_weights_on_device(cfg, 1234, device, rank, world):
+        eng.bind(name, t)
+        del t
+    from mtts import capi
+    capi.check(eng.lib.mtts_weights_ready(eng._h))
+    ids, mask = synth.synth_prompts(cfg, 77 + rank, B, T, audio_frac=0.5, ragged=False)
+    layers = [dict(top_k=50, top_p=0.95, temperature=1.0, repetition_penalty=1.0)] * 8
+    max_length = T + (L - n_real) + 8
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.begin(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=42 + rank)
+    eng.sync_state()
+    t_prefill = time.perf_counter() - t0
+    # ramp the KV context (untimed for the headline, reported as ramp_frames_per_s)
+    t0 = time.perf_counter()
+    done_steps = 0
+    while done_steps < ramp:
+        n = min(256, ramp - done_steps)
+        eng.step(n)
+        done_steps += n
+        st, fin = eng.sync_state()
+        assert not fin, "a dialogue finished during the ramp: synthetic weights must keep channel 0 in the speech range"
+    t_ramp = time.perf_counter() - t0
+    eng.step(W)
+    eng.sync_state()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(K)
+    st, fin = eng.sync_state()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert not fin and st == ramp + W + K, (st, fin)
+    # roofline leg: per-kernel HIP events on the launch stream for a few more steps at the same context
+    eng.profile(True)
+    eng.step(args.profile_steps)
+    eng.sync_state()
+    prof = {}
+    for which, nm in ((0, "attn_scores_kernel"), (1, "attn_pv_kernel"), (3, "decode_step")):
+        ms, n, by = eng.profile_read(which)
+        prof[nm] = dict(ms=ms, launches=n, bytes=by)
+    eng.profile(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    units = torch.tensor([float(B * K * 8)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    dt_max = float(tmax.item())
+    total_ids = float(units.item())
+
+    if rank == 0:
+        Lt = L - args.profile_steps - K // 2          # mean KV length inside the timed region
+        step_bytes, Wb, kvb = algorithmic_bytes_per_step(cfg, B, Lt)
+        value = total_ids / dt_max
+        frames = value / 8.0
+        ms_step = dt_max / K * 1e3
+        dom = max(("attn_scores_kernel", "attn_pv_kernel"), key=lambda k: prof[k]["ms"])
+        p = prof[dom]
+        avg_ms = p["ms"] / max(p["launches"], 1)
+        bytes_per_launch = p["bytes"] / max(p["launches"], 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "audio codec tokens/sec/node (decode, bf16, batch 32 @ 4k ctx)",
+            "value": value, "unit": "codec_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init weights of the ASSUMED 1.7B dims, synthetic prompts)",
+            "config": {"workload": "configs[2]: batch 32 synthetic dialogues/GPU, 4k-token KV context, top-k/top-p sampling on 8 channels, decode steps at full context",
+                       "batch_per_gpu": B, "context": L, "prompt": T, "layers": cfg["num_hidden_layers"],
+                       "hidden": cfg["hidden_size"], "parallelism": f"dp{world} (batch shard, no per-step collective)"},
+            "frames_per_s": frames, "real_time_factor": frames / 12.5,
+            "step_algorithmic_bytes": step_bytes,
+            "step_hbm_roofline_frac": (step_bytes / (dt_max / K)) / 1e9 / HBM_PEAK_GBS,
+            "ramp_frames_per_s": B * ramp / t_ramp if ramp else None,
+            "prefill_s": t_prefill, "setup_s": time.perf_counter() - t_setup,
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launches": p["launches"]},
+            "kernels": {k: {"avg_ms": v["ms"] / max(v["launches"], 1), "launches": v["launches"],
+                            "GBps": (v["bytes"] / max(v["launches"], 1)) / (v["ms"] / max(v["launches"], 1) * 1e-3) / 1e9
+                            if v["ms"] > 0 and v["bytes"] else None} for k, v in prof.items()},
+        }
+        if args.layers:
+            out["invalid"] = "depth overridden with --layers"
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                import threadpoolctl
+                cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) if threadpoolctl.threadpool_info() else os.cpu_count()
+            except Exception:
+                cores = os.cpu_count()
+            st_time, per_layer, heads_t = cpu_baseline(cfg, B, L)
+            out["cpu_baseline"] = {"value": B * 8 / st_time, "unit": "codec_tokens/s", "cores": cores, "kind": "port",
+                                   "sample": f"numpy oracle, 1 of {cfg['num_hidden_layers']} layers at full width + 8 heads, "
+                                             f"batch {B} at KV length {L}, best of 2 decode steps; per-layer time "
+                                             f"({per_layer:.3f} s) scaled to full depth, heads {heads_t:.3f} s"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

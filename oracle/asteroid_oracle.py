@@ -207,6 +207,18 @@ class AsteroidOracle:
         """ids [B,S,8]; positions [B,S] int; key_mask [B,L_total] (1 = real token)
         over every cache slot including the S new ones.  Returns logits list
         (8 x [B,V_c] fp32 for the last position, or [B,S,V_c])."""
+        x = self.forward_hidden(ids, positions, key_mask)
+        if not all_positions:
+            x = x[:, -1]
+        return self.heads(x)
+
+    def heads(self, x):
+        """reference modeling_asteroid.py:412 (8 tied heads), logits .float() (:123)."""
+        return [self.linear(x, self.w[f"model.embedding_list.{c}.weight"]).astype(F32)
+                for c in range(self.cfg["channels"])]
+
+    def forward_hidden(self, ids, positions, key_mask):
+        """Embedding sum + decoder stack + final norm -> [B,S,H]."""
         cfg = self.cfg
         B, S, _ = ids.shape
         nq, nkv, D = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
@@ -248,11 +260,7 @@ class AsteroidOracle:
             up = self.linear(hn, self.w[p + "mlp.up_proj.weight"])
             act = self.r(gt / (F32(1) + np.exp(-gt, dtype=F32)))
             x = self.r(x + self.linear(self.r(act * up), self.w[p + "mlp.down_proj.weight"]))
-        x = self.rmsnorm(x, self.w["model.language_model.norm.weight"])
-        if not all_positions:
-            x = x[:, -1]
-        return [self.linear(x, self.w[f"model.embedding_list.{c}.weight"]).astype(F32)
-                for c in range(cfg["channels"])]
+        return self.rmsnorm(x, self.w["model.language_model.norm.weight"])
 
     # ---- the decode loop (reference modeling_asteroid.py:83-169) ----------
     def generate(self, input_ids, attention_mask, max_length, layers=None,
