@@ -43,12 +43,17 @@ int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const 
                 int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, pad; };
 struct LoopState { int32_t step, done, base_length, max_length, tf_len, B, error, pad; };
+struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; };
+#define SAMP_CAND 4096
+#define SAMP_NS 32
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps,
                    int bm_words, const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions,
-                   int32_t* err, int B, hipStream_t st);
+                   int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, hipStream_t st);
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
-                          int32_t* decisions, int32_t* err, hipStream_t st);
+                          int32_t* decisions, int32_t* err, const SampleScratch& sc, hipStream_t st);
+static int alloc_scratch(SampleScratch& sc, int rows);
+static void free_scratch(SampleScratch& sc);
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
                    LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
@@ -118,6 +123,8 @@ struct MttsEngine {
     uint32_t* d_bitmaps = nullptr;
     int bm_words = 0;
     MttsSamplerCfg* d_scfg = nullptr;
+    SampleScratch sscr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ch0_sampled = 0;
     int32_t* d_pf_tokens = nullptr;     // prefill staging
     RowMeta* d_pf_meta = nullptr;
     size_t pf_cap_rows = 0;
@@ -152,11 +159,25 @@ static int dalloc(T** p, size_t n, bool zero = true) {
         if (_r) return _r; \
     } while (0)
 
+static int alloc_scratch(SampleScratch& sc, int rows) {
+    TRY(dalloc(&sc.hist, (size_t)rows * 2048));
+    TRY(dalloc(&sc.slice_val, (size_t)rows * SAMP_NS));
+    TRY(dalloc(&sc.slice_idx, (size_t)rows * SAMP_NS));
+    TRY(dalloc(&sc.cand_val, (size_t)rows * SAMP_CAND));
+    TRY(dalloc(&sc.cand_idx, (size_t)rows * SAMP_CAND));
+    TRY(dalloc(&sc.cand_n, (size_t)rows));
+    return 0;
+}
+static void free_scratch(SampleScratch& sc) {
+    hipFree(sc.hist); hipFree(sc.slice_val); hipFree(sc.slice_idx); hipFree(sc.cand_val); hipFree(sc.cand_idx); hipFree(sc.cand_n);
+}
+
 int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out) {
     if (!c || !out) return fail(MTTS_EINVAL, "null argument");
     if (c->head_dim != MTTS_HD) return fail(MTTS_EINVAL, "head_dim must be 128 (got %d)", c->head_dim);
     if (c->channels != 8) return fail(MTTS_EINVAL, "channels must be 8");
     if (c->hidden_size % 16 || c->intermediate_size % 16) return fail(MTTS_EINVAL, "hidden/intermediate must be multiples of 16");
+    if (c->hidden_size > 8192) return fail(MTTS_EINVAL, "hidden_size > 8192 not built (resid_norm keeps a row in registers)");
     if (c->num_attention_heads % c->num_key_value_heads) return fail(MTTS_EINVAL, "bad GQA ratio");
     int G = c->num_attention_heads / c->num_key_value_heads;
     if (G != 1 && G != 2 && G != 4) return fail(MTTS_EINVAL, "GQA group %d not built (1,2,4)", G);
@@ -235,6 +256,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->bm_words = (e->V0 + 31) / 32;
     TRY(dalloc(&e->d_bitmaps, (size_t)MTTS_MAXR * 8 * e->bm_words));
     TRY(dalloc(&e->d_scfg, 8));
+    TRY(alloc_scratch(e->sscr, MTTS_MAXR));
     *out = e;
     return MTTS_OK;
 }
@@ -255,6 +277,7 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
                     e->d_pf_meta};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_ls) hipHostFree(e->h_ls);
+    free_scratch(e->sscr);
     for (int w = 0; w < PROF_N; ++w) for (auto& pr : e->ev[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete e;
     return MTTS_OK;
@@ -500,7 +523,11 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         std::vector<int32_t> tf((size_t)MTTS_MAXR * 7 * 8, 0);
         for (int b = 0; b < B; ++b)
             for (int s = 0; s < 7; ++s)
-                for (int c = 0; c < 8; ++c) tf[((size_t)b * 7 + s) * 8 + c] = (int32_t)ids[((size_t)b * T + base + s) * 8 + c];
+                for (int c = 0; c < 8; ++c) {
+                    int64_t tk = ids[((size_t)b * T + base + s) * 8 + c];
+                    if (tk < 0 || tk >= (c == 0 ? e->V0 : e->Vs)) return fail(MTTS_EINVAL, "token %lld out of range on channel %d (delayed tail)", (long long)tk, c);
+                    tf[((size_t)b * 7 + s) * 8 + c] = (int32_t)tk;
+                }
         HIPCHK(hipMemcpyAsync(e->d_tf, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
         std::vector<SeqState> ss(MTTS_MAXR, SeqState{-1, 0, 0, 0});
         for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0};
@@ -511,6 +538,9 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         std::vector<RowMeta> dm(MTTS_MAXR, RowMeta{-1, 0, 0, 0});
         HIPCHK(hipMemcpyAsync(e->d_meta, dm.data(), dm.size() * sizeof(RowMeta), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->d_scfg, sampler, 8 * sizeof(MttsSamplerCfg), hipMemcpyHostToDevice, st));
+        e->ch0_sampled = sampler[0].do_sample ? 1 : 0;
+        HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)MTTS_MAXR * 2048 * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)MTTS_MAXR * 4, st));
         HIPCHK(hipStreamSynchronize(st));   // host vectors above go out of scope
     }
     // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
@@ -530,7 +560,7 @@ static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
         hipEvent_t ev = nullptr;
         prof_begin(e, PROF_STEP, st, &ev);
         launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
-                      e->seed, e->d_decisions, &e->d_ls->error, e->B, st);
+                      e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled, st);
         launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
                       e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, nullptr, e->cfg.eos_token_id,
                       e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, e->max_steps, st);
@@ -557,7 +587,7 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->h_ls, e->d_ls, sizeof(LoopState), hipMemcpyDeviceToHost, S(stream)));
     HIPCHK(hipStreamSynchronize(S(stream)));
-    if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 2048 tokens survive top-k (set top_k <= 2048)", e->h_ls->error);
+    if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 4096 candidate tokens (set top_k so that the k-th score's radix bin holds <= 4096 tokens)", e->h_ls->error);
     if (steps_done) *steps_done = e->h_ls->step;
     if (all_finished) *all_finished = e->h_ls->done;
     return MTTS_OK;
@@ -609,7 +639,11 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
         std::vector<int32_t> f((size_t)e->max_steps * MTTS_MAXR * 8, -1);
         for (int s = 0; s < e->max_steps && base + s < forced_len; ++s)
             for (int b = 0; b < B; ++b)
-                for (int c = 0; c < 8; ++c) f[((size_t)s * MTTS_MAXR + b) * 8 + c] = (int32_t)forced[((size_t)b * forced_len + base + s) * 8 + c];
+                for (int c = 0; c < 8; ++c) {
+                    int64_t tk = forced[((size_t)b * forced_len + base + s) * 8 + c];
+                    if (tk < 0 || tk >= (c == 0 ? e->V0 : e->Vs)) return fail(MTTS_EINVAL, "forced token %lld out of range on channel %d", (long long)tk, c);
+                    f[((size_t)s * MTTS_MAXR + b) * 8 + c] = (int32_t)tk;
+                }
         HIPCHK(hipMemcpy(e->d_forced, f.data(), f.size() * 4, hipMemcpyHostToDevice));
         e->has_forced = true;
         e->max_steps = std::min(e->max_steps, forced_len - base);
@@ -704,9 +738,13 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     TRY(dalloc(&err, 1));
     TRY(dalloc(&dec, (size_t)rows * 8));
     HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
-    launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, st);
+    if (rows > MTTS_MAXR) return fail(MTTS_EINVAL, "sample: at most 32 rows");
+    SampleScratch sc;
+    TRY(alloc_scratch(sc, MTTS_MAXR));
+    launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, sc, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    free_scratch(sc);
     std::vector<int32_t> hd((size_t)rows * 8);
     int32_t herr = 0;
     HIPCHK(hipMemcpy(hd.data(), dec, hd.size() * 4, hipMemcpyDeviceToHost));
@@ -715,6 +753,6 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     for (int r = 0; r < rows; ++r) outv[r] = hd[(size_t)r * 8 + channel];
     HIPCHK(hipMemcpy(dev_tokens, outv.data(), rows * 4, hipMemcpyHostToDevice));
     hipFree(d); hipFree(err); hipFree(dec);
-    if (herr) return fail(MTTS_EINVAL, "sample: more than 2048 tokens survive top-k");
+    if (herr) return fail(MTTS_EINVAL, "sample: more than 4096 candidate tokens");
     return MTTS_OK;
 }

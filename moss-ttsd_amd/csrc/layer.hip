@@ -67,22 +67,52 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
     __shared__ float sh[4];
     if (done && *done) return;
     const int r = blockIdx.x;
+    // each thread owns 8 consecutive elements per 2048-wide chunk (16-byte loads/stores; the 8
+    // elements are one 16-byte group of the X-fragment layout); values stay in registers.
+    constexpr int MAXC = 4;                       // H <= 8192
+    float v[MAXC][8];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float s = partial[(size_t)r * Npad + i];
-        for (int k = 1; k < ksplit; ++k) s += partial[((size_t)k * MTTS_MAXR + r) * Npad + i];
-        float v = rbf(bf2f(x[(size_t)r * H + i]) + rbf(s));
-        x[(size_t)r * H + i] = f2bf(v);
-        ss += v * v;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i0 = c * 2048 + threadIdx.x * 8;
+        if (i0 < H) {
+            const float* p0 = partial + (size_t)r * Npad + i0;
+            float4 a = *(const float4*)p0, b = *(const float4*)(p0 + 4);
+            for (int k = 1; k < ksplit; ++k) {
+                const float* pk = partial + ((size_t)k * MTTS_MAXR + r) * Npad + i0;
+                float4 a2 = *(const float4*)pk, b2 = *(const float4*)(pk + 4);
+                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+                b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+            }
+            const u32x4_t xo = *(const u32x4_t*)(x + (size_t)r * H + i0);
+            v[c][0] = rbf(bflo(xo.x) + rbf(a.x)); v[c][1] = rbf(bfhi(xo.x) + rbf(a.y));
+            v[c][2] = rbf(bflo(xo.y) + rbf(a.z)); v[c][3] = rbf(bfhi(xo.y) + rbf(a.w));
+            v[c][4] = rbf(bflo(xo.z) + rbf(b.x)); v[c][5] = rbf(bfhi(xo.z) + rbf(b.y));
+            v[c][6] = rbf(bflo(xo.w) + rbf(b.z)); v[c][7] = rbf(bfhi(xo.w) + rbf(b.w));
+            u32x4_t xn;
+            xn.x = pack2(v[c][0], v[c][1]); xn.y = pack2(v[c][2], v[c][3]);
+            xn.z = pack2(v[c][4], v[c][5]); xn.w = pack2(v[c][6], v[c][7]);
+            *(u32x4_t*)(x + (size_t)r * H + i0) = xn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
+        }
     }
     float tot = block_sum_256(ss, sh);
     float inv = 1.0f / sqrtf(tot / (float)H + eps);
     const RowMeta m = meta[r];
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float v = bf2f(x[(size_t)r * H + i]);
-        uint16_t y = f2bf(bf2f(norm_w[i]) * rbf(v * inv));
-        if (xn_packed) xn_packed[xpack_off(r, i)] = y;
-        if (hlast && m.seq >= 0 && m.last) hlast[(size_t)m.seq * H + i] = y;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i0 = c * 2048 + threadIdx.x * 8;
+        if (i0 < H) {
+            const u32x4_t w = *(const u32x4_t*)(norm_w + i0);
+            u32x4_t y;
+            y.x = pack2(bflo(w.x) * rbf(v[c][0] * inv), bfhi(w.x) * rbf(v[c][1] * inv));
+            y.y = pack2(bflo(w.y) * rbf(v[c][2] * inv), bfhi(w.y) * rbf(v[c][3] * inv));
+            y.z = pack2(bflo(w.z) * rbf(v[c][4] * inv), bfhi(w.z) * rbf(v[c][5] * inv));
+            y.w = pack2(bflo(w.w) * rbf(v[c][6] * inv), bfhi(w.w) * rbf(v[c][7] * inv));
+            if (xn_packed) *(u32x4_t*)(xn_packed + xpack_off(r, i0)) = y;
+            if (hlast && m.seq >= 0 && m.last) *(u32x4_t*)(hlast + (size_t)m.seq * H + i0) = y;
+        }
     }
 }
 

@@ -9,14 +9,12 @@
 //
 // Draw definition (torch.multinomial's stream cannot be reproduced): Philox4x32-10,
 // key = seed, counter = (step, row, channel, 0), u = (x0 >> 8) * 2^-24; kept tokens
-// are walked in ascending token id and the first whose running sum of
+// are walked in descending score and the first whose running sum of
 // exp(score - max) exceeds u * total is taken.  oracle/asteroid_oracle.py
 // (sample_from_scores) states the same rule.
 #include "common.h"
 #include "../../include/mtts.h"
 
-#define SAMP_THREADS 1024
-#define SAMP_CAP 2048     // max candidates that survive top-k (ties included)
 
 struct SeqState {           // one per sequence slot, device resident
     int32_t nas;            // needs_additional_steps
@@ -69,208 +67,321 @@ __device__ __forceinline__ float proc_score(const uint16_t* __restrict__ logits,
     return s;
 }
 
-// grid = (B, 8); block 1024.  One block handles one (row, channel).
-__global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(
-    const uint16_t* __restrict__ logits0 /*[32][V0]*/, const uint16_t* __restrict__ logits17 /*[32][7][Vs_pad]*/,
-    int V0, int Vs, int Vs_pad, const uint32_t* __restrict__ bitmaps /*[B][8][bm_words]*/, int bm_words,
-    const MttsSamplerCfg* __restrict__ cfgs /*[8]*/, const LoopState* __restrict__ ls, uint64_t seed,
-    int32_t* __restrict__ decisions /*[B][8]*/, int32_t* __restrict__ err, int single_vocab, int single_mask,
-    int single_step, int single_channel) {
-    __shared__ uint32_t hist[2048];
-    __shared__ float cval[SAMP_CAP];
-    __shared__ int cidx[SAMP_CAP];
-    __shared__ float shf[SAMP_THREADS / 64];
-    __shared__ int shi[SAMP_THREADS / 64];
-    __shared__ uint32_t sh_u[4];
-    __shared__ float sh_f[4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int b = blockIdx.x;
-    int c, step, V, mask_id;
+// ---------------------------------------------------------------------------
+// Sampler = three short kernels per step.
+//   A sample_scan_kernel    (big vocab only, grid (NS,B)): per-slice argmax + 11-bit
+//                            radix histogram of the processed scores (global, per row)
+//   B sample_collect_kernel (big vocab only, grid (NS,B)): bin b0 that holds the k-th
+//                            largest score; every token in bins >= b0 is appended to the
+//                            row's candidate list (a superset of the top-k set)
+//   C sample_final_kernel   (grid (8,B)): candidates -> LDS, bitonic sort by
+//                            (score asc, id asc), exact top-k threshold, top-p cut on
+//                            the ascending cumulative softmax, Philox draw.
+// Channels 1..7 (1025 tokens) skip A/B: kernel C reads the logits straight into LDS.
+// Draw order: kept tokens from the highest score down (ties: higher id first); the
+// first whose running sum of exp(score - max) exceeds u * total wins.
+// ---------------------------------------------------------------------------
+#define SAMP_T 256
+#define SAMP_CAND 4096
+#define SAMP_NS 32
+
+struct SampleScratch {
+    uint32_t* hist;        // [32][2048]
+    float* slice_val;      // [32][SAMP_NS]
+    int32_t* slice_idx;    // [32][SAMP_NS]
+    float* cand_val;       // [32][SAMP_CAND]
+    int32_t* cand_idx;     // [32][SAMP_CAND]
+    uint32_t* cand_n;      // [32]
+};
+
+struct SampleCtx {         // resolved per (row, channel)
     const uint16_t* lg;
+    const uint32_t* bm;
+    int V, mask_id, step, c;
+    float penalty, temp;
+};
+
+__device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const uint16_t* logits0,
+                                           const uint16_t* logits17, int V0, int Vs, int Vs_pad,
+                                           const uint32_t* bitmaps, int bm_words, const MttsSamplerCfg* cfgs,
+                                           const LoopState* ls, int single_vocab, int single_mask, int single_step,
+                                           int single_channel) {
     if (single_vocab > 0) {            // unit-test entry: one logits matrix [rows][vocab]
-        c = single_channel; step = single_step; V = single_vocab; mask_id = single_mask;
-        lg = logits0 + (size_t)b * V;
+        x.c = single_channel; x.step = single_step; x.V = single_vocab; x.mask_id = single_mask;
+        x.lg = logits0 + (size_t)b * x.V;
+        x.bm = bitmaps ? bitmaps + (size_t)b * bm_words : nullptr;
     } else {
-        if (ls->done) return;
-        c = blockIdx.y; step = ls->step;
-        V = (c == 0) ? V0 : Vs;
-        lg = (c == 0) ? logits0 + (size_t)b * V0 : logits17 + ((size_t)b * 7 + (c - 1)) * Vs_pad;
+        if (ls->done) return false;
+        x.c = c_in; x.step = ls->step;
+        x.V = (x.c == 0) ? V0 : Vs;
+        x.lg = (x.c == 0) ? logits0 + (size_t)b * V0 : logits17 + ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
         // modeling_asteroid.py:124-128 (hard-coded ids 1024 / 152694 as in the reference)
-        mask_id = -1;
-        if (c != 0 && step >= c) mask_id = 1024;
-        if (c == 0 && step <= 6) mask_id = 152694;
+        x.mask_id = -1;
+        if (x.c != 0 && x.step >= x.c) x.mask_id = 1024;
+        if (x.c == 0 && x.step <= 6) x.mask_id = 152694;
+        x.bm = bitmaps ? bitmaps + ((size_t)b * 8 + x.c) * bm_words : nullptr;
     }
-    const MttsSamplerCfg cfg = cfgs[c];
-    const uint32_t* bm = nullptr;
-    if (bitmaps) bm = (single_vocab > 0) ? bitmaps + (size_t)b * bm_words : bitmaps + ((size_t)b * 8 + c) * bm_words;
-    const float penalty = (bm && cfg.repetition_penalty > 0.f) ? cfg.repetition_penalty : 0.f;
-    const float temp = cfg.temperature;
+    const MttsSamplerCfg cfg = cfgs[x.c];
+    x.penalty = (x.bm && cfg.repetition_penalty > 0.f) ? cfg.repetition_penalty : 0.f;
+    x.temp = cfg.temperature;
+    return true;
+}
 
-    // ---- pass 1: argmax (lowest index wins ties) --------------------------------
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int i = tid; i < V; i += SAMP_THREADS) {
-        float s = proc_score(lg, i, mask_id, bm, penalty, temp);
-        if (s > best || (s == best && i < besti)) { best = s; besti = i; }
-    }
+__device__ __forceinline__ void argmax_merge(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+// block-wide argmax (lowest index wins ties); result valid in every thread
+__device__ __forceinline__ void block_argmax(float& bv, int& bi, float* shf, int* shi) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(besti, o, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    if (lane == 0) { shf[wid] = best; shi[wid] = besti; }
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+    const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
-    if (tid == 0) {
-        float bv = shf[0]; int bi = shi[0];
-        for (int w = 1; w < SAMP_THREADS / 64; ++w)
-            if (shf[w] > bv || (shf[w] == bv && shi[w] < bi)) { bv = shf[w]; bi = shi[w]; }
-        sh_f[0] = bv; shi[0] = bi;
-    }
+    if ((threadIdx.x & 63) == 0) { shf[wid] = bv; shi[wid] = bi; }
     __syncthreads();
-    const float smax = sh_f[0];
-    const int amax = shi[0];
-    if (!cfg.do_sample) {
-        if (tid == 0) decisions[b * 8 + c] = amax;
-        return;
-    }
+    bv = shf[0]; bi = shi[0];
+    for (int w = 1; w < nw; ++w) argmax_merge(bv, bi, shf[w], shi[w]);
+    __syncthreads();
+}
 
-    // ---- top-k threshold: exact k-th largest score by 3-pass radix select ----------
-    uint32_t thr_key = 0;                        // keep everything by default
-    int k = cfg.top_k;
-    if (k > 0 && k < V) {
-        uint32_t prefix = 0, pmask = 0;
-        int remaining = k;
-        const int shifts[3] = {21, 10, 0};
-        const int bits[3] = {11, 11, 10};
-#pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            const int nb = 1 << bits[pass];
-            for (int i = tid; i < 2048; i += SAMP_THREADS) hist[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < V; i += SAMP_THREADS) {
-                uint32_t key = fkey(proc_score(lg, i, mask_id, bm, penalty, temp));
-                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {                       // walk bins from the top
-                int rem = remaining, bsel = 0;
-                for (int bin = nb - 1; bin >= 0; --bin) {
-                    int cnt = (int)hist[bin];
-                    if (cnt >= rem) { bsel = bin; break; }
-                    rem -= cnt;
-                }
-                sh_u[0] = (uint32_t)bsel;
-                sh_u[1] = (uint32_t)rem;
-            }
-            __syncthreads();
-            prefix |= sh_u[0] << shifts[pass];
-            pmask |= (uint32_t)(nb - 1) << shifts[pass];
-            remaining = (int)sh_u[1];
-            __syncthreads();
+__global__ __launch_bounds__(SAMP_T) void sample_scan_kernel(
+    const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, SampleScratch sc, int single_vocab,
+    int single_mask, int single_step, int single_channel) {
+    __shared__ uint32_t hist[2048];
+    __shared__ float shf[SAMP_T / 64];
+    __shared__ int shi[SAMP_T / 64];
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    SampleCtx x;
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+                    single_step, single_channel)) return;
+    const MttsSamplerCfg cfg = cfgs[x.c];
+    const bool want_hist = cfg.do_sample && cfg.top_k > 0 && cfg.top_k < x.V;
+    for (int i = tid; i < 2048; i += SAMP_T) hist[i] = 0;
+    __syncthreads();
+    const int per = (x.V + SAMP_NS - 1) / SAMP_NS;
+    const int i0 = slice * per, i1 = min(x.V, i0 + per);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = i0 + tid; i < i1; i += SAMP_T) {
+        float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
+        argmax_merge(bv, bi, s, i);
+        if (want_hist) atomicAdd(&hist[fkey(s) >> 21], 1u);
+    }
+    block_argmax(bv, bi, shf, shi);
+    if (tid == 0) { sc.slice_val[b * SAMP_NS + slice] = bv; sc.slice_idx[b * SAMP_NS + slice] = bi; }
+    if (want_hist)
+        for (int i = tid; i < 2048; i += SAMP_T)
+            if (hist[i]) atomicAdd(&sc.hist[(size_t)b * 2048 + i], hist[i]);
+}
+
+__global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
+    const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, SampleScratch sc, int single_vocab,
+    int single_mask, int single_step, int single_channel) {
+    __shared__ uint32_t wsum[SAMP_T / 64];
+    __shared__ int sh_b0;
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    SampleCtx x;
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+                    single_step, single_channel)) return;
+    const MttsSamplerCfg cfg = cfgs[x.c];
+    if (!cfg.do_sample) return;
+    int b0 = 0;                                   // no top-k: every finite score is a candidate
+    if (cfg.top_k > 0 && cfg.top_k < x.V) {
+        // thread t owns bins 8t..8t+7; suffix sums locate the bin of the k-th largest score
+        const uint32_t* h = sc.hist + (size_t)b * 2048 + tid * 8;
+        uint32_t cnt[8], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cnt[j] = h[j]; mine += cnt[j]; }
+        uint32_t suf = mine;                      // inclusive suffix sum over lanes >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += t;
         }
-        thr_key = prefix;
+        if (lane == 0) wsum[wid] = suf;
+        if (tid == 0) sh_b0 = 0;
+        __syncthreads();
+        uint32_t above_waves = 0;
+        for (int w = wid + 1; w < SAMP_T / 64; ++w) above_waves += wsum[w];
+        const uint32_t above = above_waves + suf - mine;      // scores in bins strictly above this thread's
+        const uint32_t k = (uint32_t)cfg.top_k;
+        if (above < k && above + mine >= k) {
+            uint32_t run = above;
+            for (int j = 7; j >= 0; --j) {
+                run += cnt[j];
+                if (run >= k) { sh_b0 = tid * 8 + j; break; }
+            }
+        }
+        __syncthreads();
+        b0 = sh_b0;
     }
-
-    // ---- collect survivors (score >= k-th value, not -inf) -------------------------
-    if (tid == 0) sh_u[2] = 0;
-    __syncthreads();
     const uint32_t ninf_key = fkey(-INFINITY);
-    for (int i0 = 0; i0 < V; i0 += SAMP_THREADS) {
-        int i = i0 + tid;
-        bool keep = false;
-        float s = 0.f;
-        if (i < V) {
-            s = proc_score(lg, i, mask_id, bm, penalty, temp);
-            uint32_t key = fkey(s);
-            keep = key >= thr_key && key > ninf_key;
-        }
-        if (keep) {
-            uint32_t slot = atomicAdd(&sh_u[2], 1u);
-            if (slot < SAMP_CAP) { cval[slot] = s; cidx[slot] = i; }
+    const int per = (x.V + SAMP_NS - 1) / SAMP_NS;
+    const int i0 = slice * per, i1 = min(x.V, i0 + per);
+    for (int i = i0 + tid; i < i1; i += SAMP_T) {
+        float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
+        uint32_t key = fkey(s);
+        if ((int)(key >> 21) >= b0 && key > ninf_key) {
+            uint32_t slot = atomicAdd(&sc.cand_n[b], 1u);
+            if (slot < SAMP_CAND) { sc.cand_val[(size_t)b * SAMP_CAND + slot] = s; sc.cand_idx[(size_t)b * SAMP_CAND + slot] = i; }
         }
     }
+}
+
+// block-wide exclusive prefix sum of one float per thread (SAMP_T threads); returns (exclusive, total)
+__device__ __forceinline__ float block_excl_scan(float v, float* sh, float& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
     __syncthreads();
-    int n = (int)sh_u[2];
-    if (n > SAMP_CAP) {                        // loud failure: flag + argmax so that the loop stays defined
-        if (tid == 0) { atomicExch(err, 1); decisions[b * 8 + c] = amax; }
+    if (lane == 63) sh[wid] = inc;
+    __syncthreads();
+    float base = 0.f, tot = 0.f;
+    for (int w = 0; w < SAMP_T / 64; ++w) { if (w < wid) base += sh[w]; tot += sh[w]; }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
+    const uint16_t* __restrict__ logits0, const uint16_t* __restrict__ logits17, int V0, int Vs, int Vs_pad,
+    const uint32_t* __restrict__ bitmaps, int bm_words, const MttsSamplerCfg* __restrict__ cfgs,
+    const LoopState* __restrict__ ls, uint64_t seed, int32_t* __restrict__ decisions, int32_t* __restrict__ err,
+    SampleScratch sc, int big_channel0, int single_vocab, int single_mask, int single_step, int single_channel) {
+    __shared__ float cval[SAMP_CAND];
+    __shared__ int cidx[SAMP_CAND];
+    __shared__ float shf[SAMP_T / 64];
+    __shared__ int shi[SAMP_T / 64];
+    __shared__ int sh_i[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    SampleCtx x;
+    if (!sample_ctx(x, b, blockIdx.x, logits0, logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, single_vocab,
+                    single_mask, single_step, single_channel)) return;
+    const MttsSamplerCfg cfg = cfgs[x.c];
+    const bool big = single_vocab > 0 ? (single_vocab > SAMP_CAND) : (x.c == 0 && big_channel0);
+    const int out_slot = b * 8 + x.c;
+    int n = 0;
+    float smax; int amax;
+    if (big) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        if (tid < SAMP_NS) { bv = sc.slice_val[b * SAMP_NS + tid]; bi = sc.slice_idx[b * SAMP_NS + tid]; }
+        block_argmax(bv, bi, shf, shi);
+        smax = bv; amax = bi;
+        if (cfg.do_sample) {
+            n = (int)sc.cand_n[b];
+            const int nn = min(n, SAMP_CAND);
+            for (int i = tid; i < nn; i += SAMP_T) { cval[i] = sc.cand_val[(size_t)b * SAMP_CAND + i]; cidx[i] = sc.cand_idx[(size_t)b * SAMP_CAND + i]; }
+        }
+        __syncthreads();
+        // reset the per-row scratch for the next step
+        for (int i = tid; i < 2048; i += SAMP_T) sc.hist[(size_t)b * 2048 + i] = 0;
+        if (tid == 0) sc.cand_n[b] = 0;
+    } else {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        if (tid == 0) sh_i[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < x.V; i += SAMP_T) {
+            float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
+            argmax_merge(bv, bi, s, i);
+            if (cfg.do_sample && s > -INFINITY) {
+                int slot = atomicAdd(&sh_i[0], 1);
+                if (slot < SAMP_CAND) { cval[slot] = s; cidx[slot] = i; }
+            }
+        }
+        block_argmax(bv, bi, shf, shi);
+        smax = bv; amax = bi;
+        n = sh_i[0];
+    }
+    if (!cfg.do_sample) {
+        if (tid == 0) decisions[out_slot] = amax;
         return;
     }
-    // sort survivors by (score asc, token id asc): bitonic over SAMP_CAP slots padded with +inf
-    for (int i = n + tid; i < SAMP_CAP; i += SAMP_THREADS) { cval[i] = INFINITY; cidx[i] = 0x7fffffff; }
+    if (n > SAMP_CAND || n == 0) {               // loud failure: flag + argmax keeps the loop defined
+        if (tid == 0) { if (n > SAMP_CAND) atomicExch(err, 1); decisions[out_slot] = amax; }
+        return;
+    }
+    // bitonic sort of P = next_pow2(n) slots by (score asc, id asc); padding sorts last
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += SAMP_T) { cval[i] = INFINITY; cidx[i] = 0x7fffffff; }
     __syncthreads();
-    for (int kk = 2; kk <= SAMP_CAP; kk <<= 1) {
+    for (int kk = 2; kk <= P; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < SAMP_CAP; t += SAMP_THREADS) {
+            for (int t = tid; t < P; t += SAMP_T) {
                 int ixj = t ^ j;
                 if (ixj > t) {
                     bool up = ((t & kk) == 0);
                     float a = cval[t], bb = cval[ixj];
-                    int ai = cidx[t], bi = cidx[ixj];
-                    bool gt = (a > bb) || (a == bb && ai > bi);
-                    if (gt == up) { cval[t] = bb; cval[ixj] = a; cidx[t] = bi; cidx[ixj] = ai; }
+                    int ai = cidx[t], bi2 = cidx[ixj];
+                    bool gt = (a > bb) || (a == bb && ai > bi2);
+                    if (gt == up) { cval[t] = bb; cval[ixj] = a; cidx[t] = bi2; cidx[ixj] = ai; }
                 }
             }
             __syncthreads();
         }
     }
-    // ---- top-p: ascending cumulative softmax, drop cum <= 1-p, keep the last one --------
-    // (single thread walks <= SAMP_CAP sorted survivors: n is ~top_k in practice)
-    if (tid == 0) {
-        int first_keep = 0;
-        if (cfg.top_p > 0.f && cfg.top_p < 1.0f) {
-            float tot = 0.f;
-            for (int i = 0; i < n; ++i) tot += expf(cval[i] - smax);
-            float cum = 0.f;
-            const float lim = cfg.one_minus_top_p;   // float32(1.0 - top_p) computed in double by the host, as HF does
-            for (int i = 0; i < n - 1; ++i) {
-                cum += expf(cval[i] - smax) / tot;
-                if (cum <= lim) first_keep = i + 1; else break;
-            }
+    // top-k (HF TopKLogitsWarper): drop scores < k-th largest; ties with the k-th stay
+    int f0 = 0;
+    if (cfg.top_k > 0 && cfg.top_k < n) {
+        const float thr = cval[n - cfg.top_k];
+        int cnt = 0;
+        for (int i = tid; i < n; i += SAMP_T) cnt += (cval[i] < thr) ? 1 : 0;
+        float tot;
+        (void)block_excl_scan((float)cnt, shf, tot);
+        f0 = (int)tot;
+    }
+    // top-p (HF TopPLogitsWarper): ascending cumulative softmax over the survivors; drop cum <= 1-p,
+    // always keep the last (most probable) one.  Thread t owns a contiguous run of the kept range.
+    const int m = n - f0;                                  // survivors of top-k
+    const int per = (m + SAMP_T - 1) / SAMP_T;
+    int first_keep = f0;
+    if (cfg.top_p > 0.f && cfg.top_p < 1.0f) {
+        const int a0 = f0 + tid * per, a1 = min(n, a0 + per);
+        float loc = 0.f;
+        for (int i = a0; i < a1; ++i) loc += expf(cval[i] - smax);
+        float tot;
+        float base = block_excl_scan(loc, shf, tot);
+        int drop = 0;
+        float run = base;
+        for (int i = a0; i < a1; ++i) {
+            run += expf(cval[i] - smax);
+            if (i < n - 1 && run / tot <= cfg.one_minus_top_p) drop++;
         }
-        sh_u[3] = (uint32_t)first_keep;
+        float dtot;
+        (void)block_excl_scan((float)drop, shf, dtot);
+        first_keep = f0 + (int)dtot;          // cum is monotone: the dropped ones are a prefix
+    }
+    // draw: walk kept tokens from the top (position n-1 down to first_keep)
+    const int nk = n - first_keep;
+    const int perk = (nk + SAMP_T - 1) / SAMP_T;
+    const int r0 = tid * perk, r1 = min(nk, r0 + perk);    // ranks from the top
+    float loc = 0.f;
+    for (int r = r0; r < r1; ++r) loc += expf(cval[n - 1 - r] - smax);
+    float tot;
+    float base = block_excl_scan(loc, shf, tot);
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+    const float target = u * tot;
+    if (tid == 0) sh_i[1] = 0x7fffffff;
+    __syncthreads();
+    float run = base;
+    for (int r = r0; r < r1; ++r) {
+        run += expf(cval[n - 1 - r] - smax);
+        if (run > target) { atomicMin(&sh_i[1], r); break; }
     }
     __syncthreads();
-    const int first_keep = (int)sh_u[3];
-    // ---- draw: inverse CDF over kept tokens in ascending token id ------------------------
-    // re-sort kept survivors by token id (kept = [first_keep, n)): mark dropped ones +inf id
-    for (int t = tid; t < SAMP_CAP; t += SAMP_THREADS) {
-        if (t < first_keep || t >= n) { cidx[t] = 0x7fffffff; cval[t] = -INFINITY; }
-    }
-    __syncthreads();
-    for (int kk = 2; kk <= SAMP_CAP; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < SAMP_CAP; t += SAMP_THREADS) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    bool up = ((t & kk) == 0);
-                    int ai = cidx[t], bi = cidx[ixj];
-                    if ((ai > bi) == up) {
-                        float a = cval[t]; cval[t] = cval[ixj]; cval[ixj] = a;
-                        cidx[t] = bi; cidx[ixj] = ai;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
     if (tid == 0) {
-        const int nk = n - first_keep;
-        float kmax = -INFINITY;
-        for (int i = 0; i < nk; ++i) kmax = fmaxf(kmax, cval[i]);
-        double tot = 0.0;
-        for (int i = 0; i < nk; ++i) tot += (double)expf(cval[i] - kmax);
-        uint32_t rnd[4];
-        philox4x32_10((uint32_t)step, (uint32_t)b, (uint32_t)c, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-        const double u = (double)((float)(rnd[0] >> 8) * (1.0f / 16777216.0f));
-        const double target = u * tot;
-        double cum = 0.0;
-        int pick = cidx[nk - 1];
-        for (int i = 0; i < nk; ++i) {
-            cum += (double)expf(cval[i] - kmax);
-            if (cum > target) { pick = cidx[i]; break; }
-        }
-        decisions[b * 8 + c] = pick;
+        int r = sh_i[1];
+        if (r >= nk) r = nk - 1;                // u*tot rounding: fall back to the last kept token
+        decisions[out_slot] = cidx[n - 1 - r];
     }
 }
 
@@ -355,18 +466,34 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
     }
 }
 
+static SampleScratch g_dummy_scratch;
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps, int bm_words,
                    const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions, int32_t* err,
-                   int B, hipStream_t st) {
-    hipLaunchKernelGGL(sample_kernel, dim3(B, 8), dim3(SAMP_THREADS), 0, st, (const uint16_t*)logits0,
-                       (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seed, decisions, err, 0, 0, 0, 0);
+                   int B, const SampleScratch& sc, int ch0_sampled, hipStream_t st) {
+    const int big0 = V0 > SAMP_CAND ? 1 : 0;
+    if (big0) {
+        hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
+                           bitmaps, bm_words, cfgs, ls, sc, 0, 0, 0, 0);
+        if (ch0_sampled)
+            hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
+                               bitmaps, bm_words, cfgs, ls, sc, 0, 0, 0, 0);
+    }
+    hipLaunchKernelGGL(sample_final_kernel, dim3(8, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0,
+                       (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seed, decisions, err, sc,
+                       big0, 0, 0, 0, 0);
 }
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
-                          int32_t* decisions, int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(sample_kernel, dim3(rows, 1), dim3(SAMP_THREADS), 0, st, (const uint16_t*)logits,
-                       (const uint16_t*)nullptr, vocab, vocab, vocab, bitmap, bm_words, cfgs8, (const LoopState*)nullptr, seed,
-                       decisions, err, vocab, mask_id, step, channel);
+                          int32_t* decisions, int32_t* err, const SampleScratch& sc, hipStream_t st) {
+    if (vocab > SAMP_CAND) {
+        hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
+                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, sc, vocab, mask_id, step, channel);
+        hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
+                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, sc, vocab, mask_id, step, channel);
+    }
+    hipLaunchKernelGGL(sample_final_kernel, dim3(1, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits,
+                       (const uint16_t*)nullptr, vocab, vocab, vocab, bitmap, bm_words, cfgs8, (const LoopState*)nullptr,
+                       seed, decisions, err, sc, 1, vocab, mask_id, step, channel);
 }
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,

@@ -32,7 +32,7 @@ happens.  Summation ORDER inside a dot product is not part of the contract
 Sampling: torch.multinomial's stream cannot be reproduced, so sampled channels
 use the engine's documented stream instead: Philox4x32-10 keyed by the seed,
 counter (step, row, channel, 0), 24-bit uniform u, inverse CDF over the kept
-tokens in ascending token-id order.  The kept set and its probabilities follow
+tokens from the highest score down (ties: higher token id first).  The kept set and its probabilities follow
 the HF processors exactly.
 """
 from __future__ import annotations
@@ -138,12 +138,14 @@ def apply_processors(history, logits, layer_cfg):
 
 
 def sample_from_scores(scores, seed, step, channel, row0=0):
-    """Engine-defined draw: inverse CDF in ascending token id over kept tokens."""
+    """Engine-defined draw: inverse CDF over kept tokens from the highest score down
+    (ties: higher token id first)."""
     B = scores.shape[0]
     out = np.zeros(B, dtype=np.int64)
     for b in range(B):
         s = scores[b]
         kept = np.nonzero(s > -np.inf)[0]
+        kept = kept[np.lexsort((kept, s[kept]))[::-1]]     # (score asc, id asc) reversed
         e = np.exp((s[kept] - s[kept].max()).astype(F32)).astype(np.float64)
         cum = np.cumsum(e)
         u = float(philox_uniform(seed, step, row0 + b, channel))
