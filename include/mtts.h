@@ -137,6 +137,34 @@ int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,
                       int32_t mask_id, uint64_t seed, int32_t step, int32_t channel,
                       int32_t* dev_tokens, void* stream);
 
+/* ======================================================================================
+ * XY_Tokenizer decode path (codes -> 24 kHz waveform), fp32.
+ * Replaces XY_Tokenizer.inference_detokenize (XY_Tokenizer/xy_tokenizer/model.py:104-128);
+ * the 30 s-window / 20 s-stride scheduling of XY_Tokenizer.decode (model.py:195-256) stays
+ * in the host mirror, which calls mtts_codec_detokenize once per window batch.
+ * ====================================================================================== */
+typedef struct MttsCodecConfig {       /* decode-side fields of xy_tokenizer_config.yaml */
+    int32_t nq, codebook_size, rvq_dim, quant_out_dim;
+    int32_t adapter_layers, adapter_dim, adapter_heads, adapter_ffn, adapter_max_pos;
+    int32_t up_stride;
+    int32_t dec_layers, dec_dim, dec_heads, dec_ffn, dec_max_pos, mel_bins;
+    int32_t voc_dim, voc_inter, voc_layers, n_fft, hop;
+} MttsCodecConfig;
+
+typedef struct MttsCodec MttsCodec;
+const char* mtts_codec_last_error(void);
+int32_t mtts_codec_create(const MttsCodecConfig* cfg, int32_t device, MttsCodec** out);
+int32_t mtts_codec_destroy(MttsCodec* c);
+/* Bind one fp32 tensor by role name (role <- reference state-dict key and the
+ * re-layout applied); the engine copies it. */
+int32_t mtts_codec_bind(MttsCodec* c, const char* role, const float* dev_f32, int64_t n, void* stream);
+/* dev_codes int64 [nq][B][T] (T <= 375), host_lens int32 [B]; dev_wav f32 [B][T*1920]. Synchronous. */
+int32_t mtts_codec_detokenize(MttsCodec* c, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
+                              float* dev_wav, void* stream);
+/* unit test: C[M,N] = act(A[M,K] * W[N,K]^T + bias), exact-f32 MFMA */
+int32_t mtts_k_gemm_f32(const float* dev_a, const float* dev_w, const float* dev_bias, float* dev_c,
+                        int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

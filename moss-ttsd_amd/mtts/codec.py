@@ -1,0 +1,205 @@
+"""Python handle on the HIP codec decoder (csrc/codec.hip) + the loader that turns a
+reference-format XY_Tokenizer state dict into the engine's role tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+class MttsCodecConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nq", "codebook_size", "rvq_dim", "quant_out_dim",
+        "adapter_layers", "adapter_dim", "adapter_heads", "adapter_ffn", "adapter_max_pos", "up_stride",
+        "dec_layers", "dec_dim", "dec_heads", "dec_ffn", "dec_max_pos", "mel_bins",
+        "voc_dim", "voc_inter", "voc_layers", "n_fft", "hop")]
+
+
+_CODEC_SIGS = {
+    "mtts_codec_last_error": (C.c_char_p, []),
+    "mtts_codec_create": (C.c_int32, [C.POINTER(MttsCodecConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "mtts_codec_destroy": (C.c_int32, [C.c_void_p]),
+    "mtts_codec_bind": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtts_codec_detokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_k_gemm_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
+}
+capi._SIGS.update(_CODEC_SIGS)
+
+
+def _check(rc):
+    if rc != 0:
+        raise capi.MttsError(f"libmtts codec error {rc}: {capi.lib().mtts_codec_last_error().decode()}")
+
+
+def sinusoids(length, channels, max_timescale=10000):
+    """reference nn/modules.py:25-31, verbatim arithmetic (torch fp32)."""
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    st = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+def istft_basis(n_fft):
+    """irfft(n=n_fft, norm='backward') as a real matrix: frames = [Re | Im] @ basis, rows padded to 16."""
+    nb = n_fft // 2 + 1
+    k = np.arange(nb, dtype=np.float64)[:, None]
+    n = np.arange(n_fft, dtype=np.float64)[None, :]
+    ck = np.full((nb, 1), 2.0)
+    ck[0] = 1.0
+    ck[-1] = 1.0
+    ang = 2.0 * np.pi * k * n / n_fft
+    re = ck * np.cos(ang) / n_fft
+    im = -ck * np.sin(ang) / n_fft          # irfft ignores Im of DC and Nyquist: sin() is 0 there anyway
+    im[0] = 0.0
+    im[-1] = 0.0
+    ld = (2 * nb + 15) // 16 * 16
+    out = np.zeros((ld, n_fft), dtype=np.float32)
+    out[:nb] = re
+    out[nb:2 * nb] = im
+    return torch.from_numpy(out)
+
+
+def role_tensors(cfg, sd):
+    """reference state dict (names of XY_Tokenizer.state_dict()) -> {role: fp32 tensor}.
+    Every transformation is a pure re-layout except the weight-norm fold of quantizer.output_proj
+    (w = g * v / ||v||, torch weight_norm dim=0) and the q/k/v concatenation."""
+    t = lambda k: (torch.from_numpy(sd[k]) if isinstance(sd[k], np.ndarray) else sd[k]).detach().float().cpu()
+    r = {}
+    g, v = t("quantizer.output_proj.weight_g"), t("quantizer.output_proj.weight_v")
+    nrm = v.double().pow(2).sum(dim=(1, 2), keepdim=True).sqrt().float()
+    r["rvq.out.w"] = (g * v / nrm)[:, :, 0].contiguous()
+    r["rvq.out.b"] = t("quantizer.output_proj.bias")
+    for q in range(cfg["nq"]):
+        r[f"rvq.codebook.{q}"] = t(f"quantizer.quantizers.{q}.codebook")
+
+    def tlayers(src, dst, n_layers, d):
+        for n in range(n_layers):
+            s, o = f"{src}.layers.{n}.", f"{dst}.layers.{n}."
+            r[o + "qkv.w"] = torch.cat([t(s + "self_attn.q_proj.weight"), t(s + "self_attn.k_proj.weight"),
+                                        t(s + "self_attn.v_proj.weight")], 0).contiguous()
+            r[o + "qkv.b"] = torch.cat([t(s + "self_attn.q_proj.bias"), torch.zeros(d), t(s + "self_attn.v_proj.bias")])
+            r[o + "o.w"], r[o + "o.b"] = t(s + "self_attn.out_proj.weight"), t(s + "self_attn.out_proj.bias")
+            r[o + "ln1.w"], r[o + "ln1.b"] = t(s + "self_attn_layer_norm.weight"), t(s + "self_attn_layer_norm.bias")
+            r[o + "ln2.w"], r[o + "ln2.b"] = t(s + "final_layer_norm.weight"), t(s + "final_layer_norm.bias")
+            r[o + "fc1.w"], r[o + "fc1.b"] = t(s + "fc1.weight"), t(s + "fc1.bias")
+            r[o + "fc2.w"], r[o + "fc2.b"] = t(s + "fc2.weight"), t(s + "fc2.bias")
+
+    r["adapter.proj.w"], r["adapter.proj.b"] = t("post_rvq_adapter.proj.weight"), t("post_rvq_adapter.proj.bias")
+    r["adapter.pe"] = (t("post_rvq_adapter.positional_embedding") if "post_rvq_adapter.positional_embedding" in sd
+                       else sinusoids(cfg["adapter_max_pos"], cfg["adapter_dim"]).float())
+    tlayers("post_rvq_adapter", "adapter", cfg["adapter_layers"], cfg["adapter_dim"])
+    r["adapter.ln.w"], r["adapter.ln.b"] = t("post_rvq_adapter.layer_norm.weight"), t("post_rvq_adapter.layer_norm.bias")
+    r["adapter.out.w"], r["adapter.out.b"] = t("post_rvq_adapter.out_proj.weight"), t("post_rvq_adapter.out_proj.bias")
+    # ConvTranspose1d weight [Cin, Cout, k] -> GEMM rows (j, cout): W'[j*Cout+o][ci]
+    up = t("upsample.up_conv.weight")
+    r["up.w"] = up.permute(2, 1, 0).reshape(-1, up.shape[0]).contiguous()
+    r["dec.pe"] = (t("acoustic_decoder.positional_embedding") if "acoustic_decoder.positional_embedding" in sd
+                   else sinusoids(cfg["dec_max_pos"], cfg["dec_dim"]).float())
+    tlayers("acoustic_decoder", "dec", cfg["dec_layers"], cfg["dec_dim"])
+    r["dec.ln.w"], r["dec.ln.b"] = t("acoustic_decoder.layer_norm.weight"), t("acoustic_decoder.layer_norm.bias")
+    for nm in ("deconv1", "deconv2"):
+        w = t(f"acoustic_decoder.{nm}.weight")
+        r[f"dec.{nm}.w"] = w.permute(2, 1, 0).reshape(-1, w.shape[0]).contiguous()
+        r[f"dec.{nm}.b"] = t(f"acoustic_decoder.{nm}.bias")
+    # Conv1d weight [Cout, Cin, 7] -> im2col GEMM W'[o][j*Cin+c]
+    we = t("enhanced_vocos.backbone.embed.weight")
+    r["voc.embed.w"] = we.permute(0, 2, 1).reshape(we.shape[0], -1).contiguous()
+    r["voc.embed.b"] = t("enhanced_vocos.backbone.embed.bias")
+    r["voc.norm.w"], r["voc.norm.b"] = t("enhanced_vocos.backbone.norm.weight"), t("enhanced_vocos.backbone.norm.bias")
+    for n in range(cfg["voc_layers"]):
+        s, o = f"enhanced_vocos.backbone.convnext.{n}.", f"voc.blocks.{n}."
+        r[o + "dw.w"] = t(s + "dwconv.weight")[:, 0, :].t().contiguous()          # [7][C]
+        r[o + "dw.b"] = t(s + "dwconv.bias")
+        r[o + "ln.w"], r[o + "ln.b"] = t(s + "norm.weight"), t(s + "norm.bias")
+        r[o + "pw1.w"], r[o + "pw1.b"] = t(s + "pwconv1.weight"), t(s + "pwconv1.bias")
+        r[o + "pw2.w"], r[o + "pw2.b"] = t(s + "pwconv2.weight"), t(s + "pwconv2.bias")
+        r[o + "gamma"] = t(s + "gamma")
+    r["voc.final_ln.w"] = t("enhanced_vocos.backbone.final_layer_norm.weight")
+    r["voc.final_ln.b"] = t("enhanced_vocos.backbone.final_layer_norm.bias")
+    r["voc.head.w"], r["voc.head.b"] = t("enhanced_vocos.head.out.weight"), t("enhanced_vocos.head.out.bias")
+    r["istft.basis"] = istft_basis(cfg["n_fft"])
+    r["istft.window"] = (t("enhanced_vocos.head.istft.window") if "enhanced_vocos.head.istft.window" in sd
+                         else torch.hann_window(cfg["n_fft"]))
+    return r
+
+
+class CodecEngine:
+    def __init__(self, cfg: dict, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise capi.MttsError("no GPU visible: the mtts codec only runs on MI355X (no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = capi.lib()
+        c = MttsCodecConfig()
+        for name, _ in MttsCodecConfig._fields_:
+            setattr(c, name, int(cfg[name]))
+        self._h = C.c_void_p()
+        _check(self.lib.mtts_codec_create(C.byref(c), self.device.index or 0, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.lib.mtts_codec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind_state_dict(self, sd):
+        for role, t in role_tensors(self.cfg, sd).items():
+            d = t.to(device=self.device, dtype=torch.float32).contiguous()
+            _check(self.lib.mtts_codec_bind(self._h, role.encode(), d.data_ptr(), d.numel(), None))
+        torch.cuda.synchronize(self.device)
+
+    def detokenize(self, codes: torch.Tensor, lens):
+        """codes int64 [nq,B,T] on device; lens list[int] -> wav [B, T*1920] (device fp32)."""
+        nq, B, T = codes.shape
+        codes = codes.to(device=self.device, dtype=torch.int64).contiguous()
+        hop_total = self.cfg["decoder_upsample_rate"]
+        wav = torch.empty(B, T * hop_total, dtype=torch.float32, device=self.device)
+        lens_arr = (C.c_int32 * B)(*[int(x) for x in lens])
+        torch.cuda.synchronize(self.device)
+        _check(self.lib.mtts_codec_detokenize(self._h, codes.data_ptr(), lens_arr, B, T, wav.data_ptr(), None))
+        return wav
+
+    def decode(self, codes_list, overlap_seconds=10):
+        """XY_Tokenizer.decode (reference model.py:195-256): 30 s windows, keep 30-overlap seconds."""
+        c = self.cfg
+        duration = 30 - overlap_seconds
+        chunk_len = int(30 * c["input_sample_rate"] // c["encoder_downsample_rate"])
+        dur_len = int(duration * c["input_sample_rate"] // c["encoder_downsample_rate"])
+        up = c["decoder_upsample_rate"]
+        dur_wav = dur_len * up
+        B = len(codes_list)
+        maxT = max(int(x.shape[-1]) for x in codes_list)
+        codes = torch.zeros(c["nq"], B, maxT, dtype=torch.int64, device=self.device)
+        lens = []
+        for i, x in enumerate(codes_list):
+            x = torch.as_tensor(x)
+            codes[:, i, :x.shape[-1]] = x.to(self.device)
+            lens.append(int(x.shape[-1]))
+        lens_t = np.array(lens)
+        wavs = []
+        for ch in range((maxT + dur_len - 1) // dur_len):
+            start = ch * dur_len
+            end = min(start + chunk_len, maxT)
+            cl = np.clip(lens_t - start, 0, end - start)
+            if cl.max() == 0:
+                continue
+            y = self.detokenize(codes[:, :, start:end], cl.tolist())
+            out = torch.zeros(B, dur_wav, dtype=torch.float32, device=self.device)
+            for b in range(B):
+                k = int(min(cl[b] * up, dur_wav))
+                if k > 0:
+                    out[b, :k] = y[b, :k]
+            wavs.append(out)
+        if not wavs:
+            return [torch.zeros(0, device=self.device) for _ in range(B)]
+        full = torch.cat(wavs, dim=-1)
+        return [full[i, :lens[i] * up] for i in range(B)]
