@@ -1,0 +1,90 @@
+"""Drop-in surface end to end on the GPU: generation_utils.process_batch with the MI355X
+model + codec (config 1 plumbing with a stub tokenizer; there is no real checkpoint here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from mtts import synth, synth_codec  # noqa: E402
+from oracle import asteroid_oracle as ao  # noqa: E402
+from oracle import codec_oracle as co  # noqa: E402
+
+
+class Tok:
+    pad_token_id = 151643
+
+    def encode(self, s):
+        return [min(ord(c), 151000) for c in s]
+
+
+def _gp(cfg):
+    """generator_params dict (yaml shape) for a reduced-depth codec."""
+    return {"input_sample_rate": 16000, "output_sample_rate": 24000,
+            "quantizer_kwargs": {"num_quantizers": 8, "codebook_size": 1024, "rvq_dim": 512, "output_dim": 3072},
+            "post_rvq_adapter_kwargs": {"encoder_layers": cfg["adapter_layers"], "d_model": 768,
+                                        "encoder_attention_heads": 12, "encoder_ffn_dim": 3072, "max_source_positions": 375},
+            "upsample_kwargs": {"stride": 4},
+            "acoustic_decoder_kwargs": {"decoder_layers": cfg["dec_layers"], "d_model": 768, "decoder_attention_heads": 12,
+                                        "decoder_ffn_dim": 3072, "max_audio_seconds": 30, "sampling_rate": 16000,
+                                        "hop_length": 160, "stride_size": 2, "num_mel_bins": 80},
+            "vocos_kwargs": {"dim": 512, "intermediate_dim": 4096, "num_layers": cfg["voc_layers"], "n_fft": 960, "hop_size": 240}}
+
+
+def test_process_batch_text_only_end_to_end():
+    import generation_utils as gu
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 103, emb_row_sigma=0.6, speech_boost=4.0, eos_boost=1.0)
+    model = AsteroidTTSInstruct.from_state_dict(cfg, w, GenerationConfig(max_new_tokens=24, eos_token_id=cfg["eos_token_id"]))
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=2)
+    cw = synth_codec.synth_weights(ccfg, 9)
+    spt = XY_Tokenizer(_gp(ccfg), cw)
+    model = model.eval().to("cuda")
+    spt = spt.eval().to("cuda")
+    items = [{"text": "[S1]Hello there.[S2]Hi!"}, {"text": "[S1]A much longer line of dialogue for the second item."}]
+    texts, results = gu.process_batch(items, Tok(), model, spt, "cuda", "You are a speech synthesizer.", 5, use_normalize=True)
+    assert [t["index"] for t in texts] == [5, 6]
+    assert texts[0]["final_text"].startswith("<speaker1>") and texts[0]["normalized_text"] is not None
+    assert len(results) == 2
+    for r in results:
+        assert r is not None and r["sample_rate"] == 24000
+        a = r["audio_data"]
+        assert a.dim() == 2 and a.shape[0] == 1 and a.shape[1] % 1920 == 0 and a.shape[1] > 0
+        assert a.device.type == "cpu" and torch.isfinite(a).all()
+    # the same ids through the oracle's glue + codec oracle give the same waveform
+    seqs = [gu.shifting_inputs(gu.process_inputs(Tok(), spt, "You are a speech synthesizer.", t["final_text"], "cuda"), Tok())
+            for t in texts]
+    ids, mask = gu.rpadding(seqs, 8, Tok())
+    out = model.generate(input_ids=ids.cuda(), attention_mask=mask.cuda()).cpu().numpy()
+    T = ids.shape[1]
+    speech = ao.unshift_outputs(out, T - 7)
+    last = ao.find_max_valid_positions(speech)
+    orc = co.CodecOracle(ccfg, cw)
+    for i, r in enumerate(results):
+        want = orc.decode([speech[i, :last[i] + 1].T])[0]
+        got = r["audio_data"][0].numpy()
+        assert got.shape == want.shape
+        assert np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)) <= 1e-4
+    # a sample whose codec decode fails comes back as None, the others survive
+    class Broken:
+        output_sample_rate = 24000
+        def decode(self, codes_list, overlap_seconds=10):
+            if codes_list[0].shape[-1] == int(last[0]) + 1:
+                raise RuntimeError("boom")
+            return spt.decode(codes_list, overlap_seconds)
+    if int(last[0]) != int(last[1]):
+        _, res2 = gu.process_batch(items, Tok(), model, Broken(), "cuda", "You are a speech synthesizer.", 0)
+        assert res2[0] is None and res2[1] is not None
+
+
+def test_model_requires_gpu_and_bf16():
+    from modeling_asteroid import AsteroidTTSInstruct
+    cfg = synth.tiny()
+    m = AsteroidTTSInstruct.from_state_dict(cfg, {})
+    with pytest.raises(RuntimeError):
+        m.generate(input_ids=torch.zeros(1, 9, 8, dtype=torch.long), attention_mask=torch.ones(1, 9))
