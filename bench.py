@@ -104,6 +104,29 @@ def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
     return step_time, per_layer, min(t_heads)
 
 
+def codec_leg(device, windows=8, T=375, reps=3):
+    """Secondary figure (not `value`): full-depth XY_Tokenizer decoder, `windows` 30 s windows per call."""
+    import torch
+    from mtts import synth_codec
+    from mtts.codec import CodecEngine
+    cfg = synth_codec.codec_config()
+    eng = CodecEngine(cfg, device=str(device))
+    eng.bind_state_dict(synth_codec.synth_weights(cfg, 5))
+    codes = torch.randint(0, 1024, (cfg["nq"], windows, T), device=device)
+    eng.detokenize(codes, [T] * windows)          # warm-up (allocates the workspace)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.detokenize(codes, [T] * windows)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    eng.close()
+    flop = 1.14e12 * windows * (T / 375.0)        # SURVEY.md §8d: ~1.14 TFLOP per 375-code window
+    return {"ms_per_window": dt / windows * 1e3, "audio_seconds_per_s": windows * T * 0.08 / dt,
+            "tflops_fp32": flop / dt / 1e12, "frac_of_fp32_mfma_peak": flop / dt / 157.3e12,
+            "windows_per_call": windows, "codes_per_window": T}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +138,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override depth (debug only; result is marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--no-codec", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -231,6 +255,9 @@ def main():
         }
         if args.layers:
             out["invalid"] = "depth overridden with --layers"
+        if world == 1 and not args.no_codec:
+            eng.close()
+            out["codec_decode"] = codec_leg(device)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 import threadpoolctl

@@ -22,6 +22,14 @@ class MttsSamplerCfg(C.Structure):
                 ("one_minus_top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float)]
 
 
+class MttsCodecConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nq", "codebook_size", "rvq_dim", "quant_out_dim",
+        "adapter_layers", "adapter_dim", "adapter_heads", "adapter_ffn", "adapter_max_pos", "up_stride",
+        "dec_layers", "dec_dim", "dec_heads", "dec_ffn", "dec_max_pos", "mel_bins",
+        "voc_dim", "voc_inter", "voc_layers", "n_fft", "hop")]
+
+
 class MttsError(RuntimeError):
     pass
 
@@ -53,6 +61,13 @@ _SIGS = {
     "mtts_k_rmsnorm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "mtts_k_sample": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(MttsSamplerCfg),
                                   C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_codec_last_error": (C.c_char_p, []),
+    "mtts_codec_create": (C.c_int32, [C.POINTER(MttsCodecConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "mtts_codec_destroy": (C.c_int32, [C.c_void_p]),
+    "mtts_codec_bind": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtts_codec_detokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_k_gemm_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
 }
 
 

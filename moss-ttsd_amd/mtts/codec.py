@@ -10,24 +10,7 @@ import torch
 from . import capi
 
 
-class MttsCodecConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
-        "nq", "codebook_size", "rvq_dim", "quant_out_dim",
-        "adapter_layers", "adapter_dim", "adapter_heads", "adapter_ffn", "adapter_max_pos", "up_stride",
-        "dec_layers", "dec_dim", "dec_heads", "dec_ffn", "dec_max_pos", "mel_bins",
-        "voc_dim", "voc_inter", "voc_layers", "n_fft", "hop")]
-
-
-_CODEC_SIGS = {
-    "mtts_codec_last_error": (C.c_char_p, []),
-    "mtts_codec_create": (C.c_int32, [C.POINTER(MttsCodecConfig), C.c_int32, C.POINTER(C.c_void_p)]),
-    "mtts_codec_destroy": (C.c_int32, [C.c_void_p]),
-    "mtts_codec_bind": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "mtts_codec_detokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mtts_k_gemm_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_void_p]),
-}
-capi._SIGS.update(_CODEC_SIGS)
+MttsCodecConfig = capi.MttsCodecConfig
 
 
 def _check(rc):
