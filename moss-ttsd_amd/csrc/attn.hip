@@ -80,15 +80,17 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     }
 }
 
-// grid = (ceil(pages/ATT_PB), nkv, R); block 256.  V page is [token][128]: lane l
-// covers d = 8*(l&15).. of token 4*it + (l>>4): one contiguous KiB per instruction.
+// grid = (ceil(pages/ATT_PB), nkv, R); block 256.  V page is [token pair][d][2]: one dword holds
+// (v[2i][d], v[2i+1][d]) so that P.V is a v_dot2c_f32_bf16 against the packed (already bf16-rounded,
+// hence exact) probability pair: out[d] += p[2i]*v[2i][d] + p[2i+1]*v[2i+1][d].  Lane l covers
+// d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
 template <int G>
 __global__ __launch_bounds__(256) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, const u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
     int max_pages, int nchunks_max, int nq, int nkv, const int32_t* __restrict__ done) {
     __shared__ float red[4][G][MTTS_HD];
-    __shared__ float pbuf[4][G][MTTS_PAGE];
+    __shared__ uint16_t pbuf[4][G][MTTS_PAGE];
     if (done && *done) return;
     const int r = blockIdx.z, kvh = blockIdx.y, chunk = blockIdx.x;
     const RowMeta m = meta[r];
@@ -112,23 +114,23 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
         M[g] = mx;
         S[g] = sm;
     }
-    float acc[G][8];
+    float acc[G][4];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
-    const int sub = lane >> 4, dl = lane & 15;
+        for (int i = 0; i < 4; ++i) acc[g][i] = 0.f;
+    const int sub = lane >> 5, dl = lane & 31;
 #pragma unroll 1
     for (int pp = 0; pp < ATT_PB / 4; ++pp) {
         const int pg = chunk * ATT_PB + wave * (ATT_PB / 4) + pp;
         if (pg >= npages) break;
         const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + sub * 16 + dl;
+        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
         u32x4_t vv[16];
 #pragma unroll
         for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
-        // lane t rounds the probability of token pg*64+t once; the 16 lanes that share a
-        // token in the V loop read it back from LDS (same wave: LDS ops are ordered).
+        // lane t rounds the probability of token pg*64+t once (bf16, as the reference stores it);
+        // the V loop reads pairs back from LDS (same wave: LDS ops are ordered).
         {
             const int tok = pg * MTTS_PAGE + lane;
 #pragma unroll
@@ -136,21 +138,21 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
                 float p = 0.f;
                 if (tok < len) {
                     float s = bf2f(scores[((size_t)r * nq + kvh * G + g) * Lmax + tok]);
-                    p = rbf(expf(s - M[g]) / S[g]);
+                    p = expf(s - M[g]) / S[g];
                 }
-                pbuf[wave][g][lane] = p;
+                pbuf[wave][g][lane] = f2bf(p);
             }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            float e[8] = {bflo(vv[it].x), bfhi(vv[it].x), bflo(vv[it].y), bfhi(vv[it].y),
-                          bflo(vv[it].z), bfhi(vv[it].z), bflo(vv[it].w), bfhi(vv[it].w)};
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float p = pbuf[wave][g][it * 4 + sub];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[g][i] += p * e[i];
+                const uint32_t pp2 = ((const uint32_t*)&pbuf[wave][g][0])[it * 2 + sub];
+                acc[g][0] = dot2bf(vv[it].x, pp2, acc[g][0]);
+                acc[g][1] = dot2bf(vv[it].y, pp2, acc[g][1]);
+                acc[g][2] = dot2bf(vv[it].z, pp2, acc[g][2]);
+                acc[g][3] = dot2bf(vv[it].w, pp2, acc[g][3]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -158,11 +160,10 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             float v = acc[g][i];
-            v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (sub == 0) red[wave][g][dl * 8 + i] = v;
+            if (sub == 0) red[wave][g][dl * 4 + i] = v;
         }
     __syncthreads();
     for (int i = threadIdx.x; i < G * MTTS_HD; i += 256) {

@@ -23,6 +23,7 @@
 struct GemmPlan { int waves, ksplit, kt_per_split, kt_per_wave; };
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU = 2 };
 GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit);
+GemmPlan mtts_plan_gemm_forced(int Npad, int K, int ksplit, int waves);
 void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                  float* partial, uint16_t* out, hipStream_t st);
 void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st);
@@ -754,5 +755,36 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     HIPCHK(hipMemcpy(dev_tokens, outv.data(), rows * 4, hipMemcpyHostToDevice));
     hipFree(d); hipFree(err); hipFree(dec);
     if (herr) return fail(MTTS_EINVAL, "sample: more than 4096 candidate tokens");
+    return MTTS_OK;
+}
+
+// Tuning hook (not part of the product path): average time of one skinny-GEMM launch over `copies`
+// distinct weight buffers (so that no launch finds its weights in L2 / Infinity Cache).
+extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,
+                                     int32_t iters, float* avg_us) {
+    if (N % 32 || K % 16 || copies < 1 || iters < 1 || !avg_us) return fail(MTTS_EINVAL, "gemm_bench: bad argument");
+    GemmPlan p = (ksplit > 0 && waves > 0) ? mtts_plan_gemm_forced(N, K, ksplit, waves) : mtts_plan_gemm(N, K, ksplit);
+    std::vector<uint16_t*> w(copies, nullptr);
+    for (auto& q : w) { TRY(dalloc(&q, (size_t)N * K, false)); HIPCHK(hipMemset(q, 0x3c, (size_t)N * K * 2)); }
+    uint16_t *x = nullptr, *out = nullptr;
+    float* part = nullptr;
+    TRY(dalloc(&x, (size_t)MTTS_MAXR * K, false));
+    HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_MAXR * K * 2));
+    TRY(dalloc(&out, (size_t)MTTS_MAXR * N));
+    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_MAXR * N));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < copies; ++i) launch_gemm(epi, p, w[i], x, K, N, N, part, out, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) launch_gemm(epi, p, w[i % copies], x, K, N, N, part, out, nullptr);
+    hipEventRecord(e1, nullptr);
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *avg_us = ms * 1000.f / iters;
+    for (auto q : w) hipFree(q);
+    hipFree(x); hipFree(out); hipFree(part);
+    hipEventDestroy(e0); hipEventDestroy(e1);
     return MTTS_OK;
 }

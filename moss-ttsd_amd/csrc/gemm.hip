@@ -185,6 +185,15 @@ void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int
 }
 
 GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit) { return plan_gemm(Npad, K, want_ksplit); }
+GemmPlan mtts_plan_gemm_forced(int Npad, int K, int ksplit, int waves) {
+    GemmPlan p;
+    int KT = K / 16;
+    p.ksplit = ksplit;
+    p.kt_per_split = (KT + ksplit - 1) / ksplit;
+    p.waves = waves;
+    p.kt_per_wave = (p.kt_per_split + waves - 1) / waves;
+    return p;
+}
 
 void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st) {
     size_t total = (size_t)rows_pad * cols / 8;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
 // the paged cache (replaces DynamicCache.update's torch.cat, :258-259).
 //   K page layout: [page][kvh][d/8][token 0..63][8]   (token-major inner: the
 //   score kernel reads one token per lane with no cross-lane reduction)
-//   V page layout: [page][kvh][token 0..63][128]
+//   V page layout: [page][kvh][token pair 0..31][d 0..127][2]  (P.V as v_dot2c against packed p pairs)
 // grid = (R, nq + 2*nkv), block 64 (lane l owns d = l and d = l+64).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void qkv_post_kernel(
@@ -149,9 +149,10 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     const int tok = m.pos & 63;
     if (h >= nq + nkv) {   // V head: no norm, no rope
         const int kvh = h - nq - nkv;
-        uint16_t* dst = vcache + (((size_t)page * nkv + kvh) * MTTS_PAGE + tok) * MTTS_HD;
-        dst[l] = f2bf(a);
-        dst[l + 64] = f2bf(b);
+        // V page layout [token pair][d][2]: element (tok, d) at ((tok>>1)*128 + d)*2 + (tok&1)
+        uint16_t* dst = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD) + (size_t)(tok >> 1) * (MTTS_HD * 2) + (tok & 1);
+        dst[2 * l] = f2bf(a);
+        dst[2 * (l + 64)] = f2bf(b);
         return;
     }
     const uint16_t* nw = (h < nq) ? qnorm_w : knorm_w;
