@@ -21,6 +21,9 @@ def codec_config(**over):
         up_stride=4,
         dec_layers=12, dec_dim=768, dec_heads=12, dec_ffn=3072, dec_max_pos=1500, mel_bins=80,
         voc_dim=512, voc_inter=4096, voc_layers=30, n_fft=960, hop=240,
+        # encode side: mel front-end, two OmniAudioEncoders, adapters, down-conv, RVQ search
+        mel_n_fft=400, mel_hop=160, mel_frames=3000, enc_layers=12, enc_dim=768, enc_heads=12, enc_ffn=3072,
+        enc_max_pos=1500, sem_adapter_layers=4, pre_rvq_layers=4, down_pool=4,
     )
     cfg.update(over)
     return cfg
@@ -28,7 +31,7 @@ def codec_config(**over):
 
 def reduced(**over):
     """Same widths, fewer layers: what the fixtures run (the kernels see real shapes)."""
-    base = dict(adapter_layers=1, dec_layers=2, voc_layers=3)
+    base = dict(adapter_layers=1, dec_layers=2, voc_layers=3, enc_layers=2, sem_adapter_layers=1, pre_rvq_layers=1)
     base.update(over)
     return codec_config(**base)
 
@@ -45,7 +48,15 @@ def from_yaml_generator_params(gp):
         dec_ffn=d["decoder_ffn_dim"],
         dec_max_pos=(d["max_audio_seconds"] * d["sampling_rate"] // d["hop_length"]) // d["stride_size"],
         mel_bins=d["num_mel_bins"], voc_dim=v["dim"], voc_inter=v["intermediate_dim"], voc_layers=v["num_layers"],
-        n_fft=v["n_fft"], hop=v["hop_size"])
+        n_fft=v["n_fft"], hop=v["hop_size"],
+        mel_n_fft=gp["feature_extractor_kwargs"]["n_fft"], mel_hop=gp["feature_extractor_kwargs"]["hop_length"],
+        mel_frames=gp["feature_extractor_kwargs"]["nb_max_frames"],
+        enc_layers=gp["semantic_encoder_kwargs"]["encoder_layers"], enc_dim=gp["semantic_encoder_kwargs"]["d_model"],
+        enc_heads=gp["semantic_encoder_kwargs"]["encoder_attention_heads"], enc_ffn=gp["semantic_encoder_kwargs"]["encoder_ffn_dim"],
+        enc_max_pos=(gp["semantic_encoder_kwargs"]["max_audio_seconds"] * gp["semantic_encoder_kwargs"]["sampling_rate"]
+                     // gp["semantic_encoder_kwargs"]["hop_length"]) // gp["semantic_encoder_kwargs"]["stride_size"],
+        sem_adapter_layers=gp["semantic_encoder_adapter_kwargs"]["encoder_layers"],
+        pre_rvq_layers=gp["pre_rvq_adapter_kwargs"]["encoder_layers"], down_pool=gp["downsample_kwargs"]["avg_pooler"])
 
 
 def _tlayer(prefix, d, ffn):
@@ -98,10 +109,40 @@ def weight_shapes(cfg):
     return out
 
 
-def synth_weights(cfg, seed):
+def encoder_weight_shapes(cfg):
+    """Encode-side tensors (reference state-dict names)."""
+    c = cfg
+    d, mel = c["enc_dim"], c["mel_bins"]
+    out = []
+    for enc in ("semantic_encoder", "acoustic_encoder"):
+        out += [(f"{enc}.conv1.weight", (d, mel, 3), "lin"), (f"{enc}.conv1.bias", (d,), "bias"),
+                (f"{enc}.conv2.weight", (d, d, 3), "lin"), (f"{enc}.conv2.bias", (d,), "bias")]
+        for n in range(c["enc_layers"]):
+            out += _tlayer(f"{enc}.layers.{n}.", d, c["enc_ffn"])
+        out += [(f"{enc}.layer_norm.weight", (d,), "norm"), (f"{enc}.layer_norm.bias", (d,), "bias")]
+    for n in range(c["sem_adapter_layers"]):
+        out += _tlayer(f"semantic_encoder_adapter.layers.{n}.", d, c["enc_ffn"])
+    out += [("semantic_encoder_adapter.layer_norm.weight", (d,), "norm"), ("semantic_encoder_adapter.layer_norm.bias", (d,), "bias"),
+            ("pre_rvq_adapter.proj.weight", (d, 2 * d), "lin"), ("pre_rvq_adapter.proj.bias", (d,), "bias")]
+    for n in range(c["pre_rvq_layers"]):
+        out += _tlayer(f"pre_rvq_adapter.layers.{n}.", d, c["enc_ffn"])
+    out += [("pre_rvq_adapter.layer_norm.weight", (d,), "norm"), ("pre_rvq_adapter.layer_norm.bias", (d,), "bias")]
+    di = d * c["down_pool"]
+    out += [("downsample.gate_proj.weight", (di, d, c["down_pool"]), "lin"), ("downsample.up_proj.weight", (di, d, c["down_pool"]), "lin"),
+            ("downsample.down_proj.weight", (di, di), "lin"), ("downsample.layer_norm.weight", (di,), "norm"),
+            ("downsample.layer_norm.bias", (di,), "bias"),
+            ("quantizer.input_proj.bias", (c["rvq_dim"],), "bias"), ("quantizer.input_proj.weight_g", (c["rvq_dim"], 1, 1), "g"),
+            ("quantizer.input_proj.weight_v", (c["rvq_dim"], di, 1), "lin")]
+    return out
+
+
+def synth_weights(cfg, seed, encoder=False):
+    """Decode-side tensors; with encoder=True the encode-side ones are appended (drawn AFTER the
+    decode-side ones, so decode fixtures do not depend on the flag)."""
     rng = np.random.default_rng(seed)
     w = {}
-    for name, shape, kind in weight_shapes(cfg):
+    shapes = weight_shapes(cfg) + (encoder_weight_shapes(cfg) if encoder else [])
+    for name, shape, kind in shapes:
         if kind == "norm":
             a = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
         elif kind == "bias":
@@ -124,3 +165,17 @@ def synth_weights(cfg, seed):
 def synth_codes(cfg, seed, lengths):
     rng = np.random.default_rng(seed)
     return [rng.integers(0, cfg["codebook_size"], (cfg["nq"], int(n))).astype(np.int64) for n in lengths]
+
+
+def synth_wavs(seed, lengths, sr=16000):
+    """Band-limited noise bursts with a slow envelope: gives the mel front-end something speech-like."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for n in lengths:
+        t = np.arange(int(n)) / sr
+        x = rng.standard_normal(int(n)).astype(np.float32)
+        x = np.convolve(x, np.hanning(9).astype(np.float32) / 4.5, mode="same")
+        env = 0.5 + 0.5 * np.sin(2 * np.pi * (1.3 + rng.random()) * t + rng.random() * 6.28)
+        tone = 0.3 * np.sin(2 * np.pi * (180 + 120 * rng.random()) * t)
+        out.append((0.2 * x * env + tone * env).astype(np.float32))
+    return out

@@ -34,13 +34,13 @@ from xy_tokenizer.model import XY_Tokenizer  # noqa: E402
 STRIDE = 13
 
 
-def build_reference(cfg, w):
+def build_reference(cfg, w, encoder=False):
     gp = yaml.safe_load(open("/root/reference/XY_Tokenizer/config/xy_tokenizer_config.yaml"))["generator_params"]
-    # encoder side is never run here: shrink it so the module builds fast
+    # when the encoder side is not run, shrink it so the module builds fast
     for k in ["semantic_encoder_kwargs", "acoustic_encoder_kwargs"]:
-        gp[k]["encoder_layers"] = 1
-    gp["semantic_encoder_adapter_kwargs"]["encoder_layers"] = 1
-    gp["pre_rvq_adapter_kwargs"]["encoder_layers"] = 1
+        gp[k]["encoder_layers"] = cfg["enc_layers"] if encoder else 1
+    gp["semantic_encoder_adapter_kwargs"]["encoder_layers"] = cfg["sem_adapter_layers"] if encoder else 1
+    gp["pre_rvq_adapter_kwargs"]["encoder_layers"] = cfg["pre_rvq_layers"] if encoder else 1
     gp["post_rvq_adapter_kwargs"]["encoder_layers"] = cfg["adapter_layers"]
     gp["acoustic_decoder_kwargs"]["decoder_layers"] = cfg["dec_layers"]
     gp["vocos_kwargs"]["num_layers"] = cfg["voc_layers"]
@@ -51,7 +51,27 @@ def build_reference(cfg, w):
     dec = ("quantizer.output_proj", "quantizer.quantizers", "post_rvq_adapter", "upsample", "acoustic_decoder", "enhanced_vocos")
     bad = [k for k in missing if k.startswith(dec) and not any(s in k for s in ("inited", "cluster_size", "embed_avg", "positional_embedding", "istft.window"))]
     assert not bad, bad
+    if encoder:
+        bad = [k for k in missing if not k.startswith(dec) and not any(s in k for s in ("positional_embedding",))]
+        assert not bad, bad
+        for q in m.quantizer.quantizers:       # codebooks are buffers that count as "not initialised" by default
+            q.inited.fill_(True)
     return m
+
+
+def make_encode(name, cfg, seed, lengths):
+    """Reference XY_Tokenizer.encode (model.py:131-192) on synthetic audio -> code ids."""
+    w = synth_codec.synth_weights(cfg, seed, encoder=True)
+    m = build_reference(cfg, w, encoder=True)
+    wavs = synth_codec.synth_wavs(seed + 1, lengths)
+    with torch.no_grad():
+        res = m.encode([torch.from_numpy(x) for x in wavs], overlap_seconds=10, device=torch.device("cpu"))
+        # second-best distance margins of the first window (how safe each argmin is)
+    d = dict(cfg=json.dumps(cfg), seed=seed, lengths=np.array(lengths))
+    for i, cds in enumerate(res["codes_list"]):
+        d[f"codes{i}"] = cds.numpy().astype(np.int16)
+        print(name, i, tuple(cds.shape), cds[:, :6].tolist()[0])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
 
 
 def make(name, cfg, seed, lengths):
@@ -74,7 +94,15 @@ def make(name, cfg, seed, lengths):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     red = synth_codec.reduced()
+    if "enc" in sys.argv[1:]:
+        make_encode("codec_enc_3s", red, 11, [48000])
+        make_encode("codec_enc_ragged", red, 12, [80000, 33000])
+        make_encode("codec_enc_35s", red, 13, [560000])
+        sys.exit(0)
     make("codec_T40", red, 5, [40])
     make("codec_ragged_1win", red, 6, [375, 200])          # exactly one window + a padded row
     make("codec_T600", red, 7, [600])                      # 3 windows (starts 0, 250, 500)
     make("codec_full_T24", synth_codec.codec_config(), 8, [24])
+    make_encode("codec_enc_3s", red, 11, [48000])
+    make_encode("codec_enc_ragged", red, 12, [80000, 33000])          # batch with a shorter row
+    make_encode("codec_enc_35s", red, 13, [560000])                   # 2 windows (30 s + stride 20 s)

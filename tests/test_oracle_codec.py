@@ -53,3 +53,28 @@ def test_codec_oracle_edge_cases():
     # one code
     out = orc.decode(synth_codec.synth_codes(cfg, 3, [1]))
     assert out[0].shape[0] == 1920 and np.isfinite(out[0]).all()
+
+
+ENC_CASES = ["codec_enc_3s", "codec_enc_ragged", "codec_enc_35s"]
+
+
+@pytest.mark.parametrize("name", ENC_CASES)
+def test_codec_encode_oracle_matches_reference(golden_dir, name):
+    """Exact code ids against the reference XY_Tokenizer.encode (CPU) on synthetic audio."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth_codec.synth_weights(cfg, int(z["seed"]), encoder=True)
+    wavs = synth_codec.synth_wavs(int(z["seed"]) + 1, list(z["lengths"]))
+    got = co.CodecEncodeOracle(cfg, w).encode(wavs)
+    for i, g in enumerate(got):
+        want = z[f"codes{i}"].astype(np.int64)
+        assert g.shape == want.shape, (g.shape, want.shape)
+        assert np.array_equal(g, want), float((g != want).mean())
+
+
+def test_mel_filter_bank_matches_transformers():
+    tr = pytest.importorskip("transformers.audio_utils")
+    ref = tr.mel_filter_bank(num_frequency_bins=201, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0,
+                             sampling_rate=16000, norm="slaney", mel_scale="slaney")
+    got = co.mel_filter_bank_slaney(201, 80, 16000, 0.0, 8000.0)
+    np.testing.assert_allclose(got, ref.astype(np.float32), rtol=1e-6, atol=1e-9)
