@@ -149,6 +149,10 @@ typedef struct MttsCodecConfig {       /* decode-side fields of xy_tokenizer_con
     int32_t up_stride;
     int32_t dec_layers, dec_dim, dec_heads, dec_ffn, dec_max_pos, mel_bins;
     int32_t voc_dim, voc_inter, voc_layers, n_fft, hop;
+    /* encode side (voice-clone prompts) */
+    int32_t mel_n_fft, mel_hop, mel_frames;
+    int32_t enc_layers, enc_dim, enc_heads, enc_ffn, enc_max_pos;
+    int32_t sem_adapter_layers, pre_rvq_layers, down_pool;
 } MttsCodecConfig;
 
 typedef struct MttsCodec MttsCodec;
@@ -161,6 +165,11 @@ int32_t mtts_codec_bind(MttsCodec* c, const char* role, const float* dev_f32, in
 /* dev_codes int64 [nq][B][T] (T <= 375), host_lens int32 [B]; dev_wav f32 [B][T*1920]. Synchronous. */
 int32_t mtts_codec_detokenize(MttsCodec* c, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
                               float* dev_wav, void* stream);
+/* Encode one chunk (<= 30 s of 16 kHz audio) per row.  Replaces XY_Tokenizer.inference_tokenize
+ * (XY_Tokenizer/xy_tokenizer/model.py:55-101), log-mel included.  dev_wav f32 [B][nsamp] zero padded,
+ * host_lens int32 [B]; dev_codes int64 [nq][B][375]; host_code_lens int32 [B] (out).  Synchronous. */
+int32_t mtts_codec_tokenize(MttsCodec* c, const float* dev_wav, const int32_t* host_lens, int32_t B, int32_t nsamp,
+                            int64_t* dev_codes, int32_t* host_code_lens, void* stream);
 /* unit test: C[M,N] = act(A[M,K] * W[N,K]^T + bias), exact-f32 MFMA */
 int32_t mtts_k_gemm_f32(const float* dev_a, const float* dev_w, const float* dev_bias, float* dev_c,
                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream);

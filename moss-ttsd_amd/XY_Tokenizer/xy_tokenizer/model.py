@@ -1,7 +1,7 @@
 """Drop-in for the reference's XY_Tokenizer (XY_Tokenizer/xy_tokenizer/model.py) on MI355X:
 `load_from_checkpoint`, `.eval()`, `.to(device)`, `.decode(codes_list)`, sample-rate attributes.
-The decode branch runs on the HIP codec engine (csrc/codec.hip); `.encode` (voice-clone
-prompts) is not built yet and fails loudly."""
+Both branches run on the HIP codec engine (csrc/codec.hip): `.decode` (codes -> waveform) and
+`.encode` (voice-clone prompt audio -> codes, log-mel front-end on the device)."""
 from __future__ import annotations
 
 import torch
@@ -51,6 +51,7 @@ class XY_Tokenizer:
         """B x LongTensor(nq,T) -> {"syn_wav_list": B x FloatTensor(1920*T,)}  (reference model.py:195-256)."""
         return {"syn_wav_list": self._get_engine().decode(codes_list, overlap_seconds=overlap_seconds)}
 
+    @torch.inference_mode()
     def encode(self, wav_list, overlap_seconds=10, device=None):
-        raise NotImplementedError("XY_Tokenizer.encode (prompt-audio tokenisation, reference model.py:131-192) "
-                                  "is the next hot-path row and is not built in this round")
+        """B x FloatTensor(T,) at 16 kHz -> {"codes_list": B x LongTensor(nq, T//1280)}  (reference model.py:131-192)."""
+        return {"codes_list": self._get_engine().encode(wav_list, overlap_seconds=overlap_seconds)}

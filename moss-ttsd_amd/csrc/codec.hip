@@ -190,7 +190,7 @@ __global__ void add_pe_kernel(float* x, const float* pe, long n, int T, int d) {
 // when lens != null (torch.where(attention_mask, h, 0), modules.py:409,626).
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows, int C,
-                                                        float eps, const int* __restrict__ lens, int T) {
+                                                        float eps, const int* __restrict__ lens, int T, long ldy) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * C;
@@ -207,8 +207,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) y[(long)row * C + c] = zero ? 0.f : (v[i] - mu) * inv * w[c] + b[c];
+        if (c < C) y[(long)row * ldy + c] = zero ? 0.f : (v[i] - mu) * inv * w[c] + b[c];
     }
+}
+
+// LayerNorm for wide rows (C up to 16384): one 256-thread block per row.
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ y, int C, float eps) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += xr[c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mu = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float d = xr[c] - mu; q += d * d; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) y[row * C + c] = (xr[c] - mu) * inv * w[c] + b[c];
 }
 
 // Masked softmax over keys, one wave per (b, head, query) row of S [.., T, ldT].
@@ -361,6 +383,115 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames /*[B][T][n]*/,
     wav[(long)b * T * hop + s] = acc / env;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Encode-side kernels (XY_Tokenizer.inference_tokenize, reference model.py:55-101)
+// ------------------------------------------------------------------------------------
+// STFT framing of torch.stft(center=True, pad_mode="reflect") over the 30 s zero-padded chunk
+// (feature_extractor.py:78-104): frames[b,t,n] = x_reflect[t*hop + n - n_fft/2] * hann[n]
+__global__ void mel_frames_kernel(const float* __restrict__ wav, const float* __restrict__ window, float* __restrict__ fr,
+                                  int nsamp_in, int N, int nfr, int n_fft, int hop) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+        long i = (long)t * hop + n - n_fft / 2;
+        if (i < 0) i = -i;
+        if (i >= N) i = 2L * N - 2 - i;
+        const float v = (i < nsamp_in) ? wav[(long)b * nsamp_in + i] : 0.f;
+        fr[((long)b * nfr + t) * n_fft + n] = v * window[n];
+    }
+}
+// |X|^2 from the [cos | sin] DFT GEMM output; columns padded to ldp with zeros
+__global__ void power_kernel(const float* __restrict__ ri, float* __restrict__ pw, int nb, int ldri, int ldp) {
+    const long row = blockIdx.x;
+    for (int k = threadIdx.x; k < ldp; k += blockDim.x) {
+        float v = 0.f;
+        if (k < nb) { const float re = ri[row * ldri + k], im = ri[row * ldri + nb + k]; v = re * re + im * im; }
+        pw[row * ldp + k] = v;
+    }
+}
+// log10(clamp(mel,1e-10)); per-sample maximum (one block per sample)
+__global__ __launch_bounds__(256) void logmel_max_kernel(float* __restrict__ mel, float* __restrict__ mx, long per_sample) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    float* p = mel + (long)b * per_sample;
+    float m = -INFINITY;
+    for (long i = threadIdx.x; i < per_sample; i += 256) {
+        const float v = log10f(fmaxf(p[i], 1e-10f));
+        p[i] = v;
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) mx[b] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__global__ void logmel_norm_kernel(float* __restrict__ mel, const float* __restrict__ mx, long per_sample, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float m = mx[i / per_sample];
+    mel[i] = (fmaxf(mel[i], m - 8.0f) + 4.0f) / 4.0f;
+}
+// generic im2col for Conv1d(k, stride, pad) on token-major data: X[b,t][j*C+c] = x[b, t*stride + j - pad][c]
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ X, int Tin, int Tout, int C, int ksz,
+                              int stride, int pad) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int i = threadIdx.x; i < ksz * C; i += blockDim.x) {
+        const int j = i / C, c = i % C;
+        const int ts = t * stride + j - pad;
+        X[((long)b * Tout + t) * ksz * C + i] = (ts >= 0 && ts < Tin) ? x[((long)b * Tin + ts) * C + c] : 0.f;
+    }
+}
+__global__ void silu_mul_kernel(float* __restrict__ g, const float* __restrict__ u, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = g[i];
+    g[i] = (x / (1.0f + expf(-x))) * u[i];
+}
+// One RVQ stage (quantizer.py:154-191,:277-327, eval branch): nearest codebook entry of the masked
+// residual by dist = (|r|^2 - 2 r.c) + |c|^2, first index on ties; residual -= codebook[idx] * mask.
+// dot: [rows][K] from the GEMM.  One 256-thread block per row.
+__global__ __launch_bounds__(256) void vq_argmin_update_kernel(const float* __restrict__ dot, const float* __restrict__ cb,
+                                                               const float* __restrict__ cc, float* __restrict__ residual,
+                                                               int64_t* __restrict__ codes, const int* __restrict__ lens,
+                                                               int T, int K, int D) {
+    __shared__ float shv[4];
+    __shared__ int shi[4];
+    __shared__ float sh_rr;
+    const long row = blockIdx.x;
+    const bool valid = (int)(row % T) < lens[row / T];
+    float* r = residual + row * D;
+    float rr = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) rr += r[d] * r[d];
+    rr = wave_sum(rr);
+    if ((threadIdx.x & 63) == 0) shv[threadIdx.x >> 6] = rr;
+    __syncthreads();
+    if (threadIdx.x == 0) sh_rr = shv[0] + shv[1] + shv[2] + shv[3];
+    __syncthreads();
+    rr = valid ? sh_rr : 0.f;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        const float dt = valid ? dot[row * K + j] : 0.f;
+        const float nd = -((rr - 2.0f * dt) + cc[j]);
+        if (nd > best || (nd == best && j < bi)) { best = nd; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = best; shi[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    best = shv[0]; bi = shi[0];
+    for (int w = 1; w < 4; ++w)
+        if (shv[w] > best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
+    if (threadIdx.x == 0) codes[row] = bi;
+    if (valid)
+        for (int d = threadIdx.x; d < D; d += 256) r[d] -= cb[(long)bi * D + d];
+}
+
 // ------------------------------------------------------------------------------------
 // Host object
 // ------------------------------------------------------------------------------------
@@ -388,7 +519,9 @@ struct MttsCodec {
     // workspace
     size_t cap_rows = 0;        // rows at the 100 Hz stage the workspace is sized for
     int cap_B = 0, cap_T = 0;
-    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *big = nullptr, *scores = nullptr;
+    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *bufE = nullptr, *big = nullptr, *scores = nullptr;
+    float *melbuf = nullptr, *melmax = nullptr;
+    int* d_lens2 = nullptr;
     int64_t* d_codes = nullptr;
     int *d_lens = nullptr, *d_lens4 = nullptr, *d_err = nullptr;
 };
@@ -398,6 +531,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     if (c->adapter_dim % c->adapter_heads || c->dec_dim % c->dec_heads) return cfail(MTTS_EINVAL, "bad head split");
     if (c->adapter_dim > 1024 || c->dec_dim > 1024 || c->voc_dim > 1024) return cfail(MTTS_EINVAL, "row kernels hold <= 1024 channels");
     if (c->n_fft % 2 || c->hop < 1 || (c->n_fft - c->hop) % 2) return cfail(MTTS_EINVAL, "bad STFT geometry");
+    if (c->enc_dim > 1024 || (c->enc_heads && c->enc_dim % c->enc_heads)) return cfail(MTTS_EINVAL, "bad encoder width");
     CHK(hipSetDevice(device));
     MttsCodec* k = new MttsCodec();
     k->c = *c;
@@ -413,8 +547,9 @@ extern "C" int32_t mtts_codec_destroy(MttsCodec* k) {
     hipSetDevice(k->device);
     hipDeviceSynchronize();
     for (auto& kv : k->w) hipFree(kv.second);
-    float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->big, k->scores};
+    float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->bufE, k->big, k->scores, k->melbuf, k->melmax};
     for (float* p : bufs) if (p) hipFree(p);
+    if (k->d_lens2) hipFree(k->d_lens2);
     if (k->d_codes) hipFree(k->d_codes);
     if (k->d_lens) hipFree(k->d_lens);
     if (k->d_lens4) hipFree(k->d_lens4);
@@ -456,9 +591,9 @@ static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
 static int ensure_workspace(MttsCodec* k, int B, int T) {
     if (B <= k->cap_B && T <= k->cap_T) return 0;
     const MttsCodecConfig& c = k->c;
-    float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->big, k->scores};
+    float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->bufE, k->big, k->scores, k->melbuf, k->melmax};
     for (float* p : bufs) if (p) hipFree(p);
-    if (k->d_codes) { hipFree(k->d_codes); hipFree(k->d_lens); hipFree(k->d_lens4); }
+    if (k->d_codes) { hipFree(k->d_codes); hipFree(k->d_lens); hipFree(k->d_lens4); hipFree(k->d_lens2); }
     const int up = c.up_stride;
     const size_t r100 = (size_t)B * (2 * (size_t)T * up + 3);        // frames at the 100 Hz stage (+ deconv slack)
     size_t wide = std::max<size_t>({(size_t)c.quant_out_dim, (size_t)3 * c.adapter_dim, (size_t)3 * c.dec_dim,
@@ -472,6 +607,10 @@ static int ensure_workspace(MttsCodec* k, int B, int T) {
     CHK(hipMalloc((void**)&k->bufB, n_small * 4));
     CHK(hipMalloc((void**)&k->bufC, n_small * 4));
     CHK(hipMalloc((void**)&k->bufD, n_small * 4));
+    CHK(hipMalloc((void**)&k->bufE, n_small * 4));
+    CHK(hipMalloc((void**)&k->melbuf, r100 * (size_t)c.mel_bins * 4));
+    CHK(hipMalloc((void**)&k->melmax, (size_t)B * 4));
+    CHK(hipMalloc((void**)&k->d_lens2, (size_t)B * 4));
     CHK(hipMalloc((void**)&k->big, n_big * 4));
     CHK(hipMalloc((void**)&k->scores, n_sc * 4));
     CHK(hipMalloc((void**)&k->d_codes, (size_t)c.nq * B * T * 8));
@@ -494,7 +633,7 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
     NEED(w1, p + "fc1.w", (size_t)ffn * d); NEED(b1, p + "fc1.b", ffn);
     NEED(w2, p + "fc2.w", (size_t)d * ffn); NEED(b2, p + "fc2.b", d);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln1w, ln1b, tmp, rows, d, 1e-5f,
-                       (const int*)nullptr, T);
+                       (const int*)nullptr, T, (long)d);
     gemm_f32(st, false, tmp, wqkv, qkv, rows, 3 * d, d, d, d, 3 * d, bqkv);
     // S[b,h] = (q k^T) * hd^-0.5   (the reference scales q before the product, modules.py:131)
     gemm_f32(st, false, qkv, qkv + d, k->scores, T, T, hd, 3 * d, 3 * d, ldT, nullptr, 0, nullptr, nullptr, 0, 0,
@@ -507,7 +646,7 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
              B * heads, heads, (long)heads * T * ldT, (long)T * ldT, (long)T * 3 * d, hd, (long)T * d, hd);
     gemm_f32(st, false, att, wo, x, rows, d, d, d, d, d, bo, 0, nullptr, x, d);          // x += out_proj(att)
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln2w, ln2b, tmp, rows, d, 1e-5f,
-                       (const int*)nullptr, T);
+                       (const int*)nullptr, T, (long)d);
     gemm_f32(st, false, tmp, w1, k->big, rows, ffn, d, d, d, ffn, b1, 1);
     gemm_f32(st, false, k->big, w2, x, rows, d, ffn, ffn, ffn, d, b2, 0, nullptr, x, d);  // x += fc2(gelu(fc1))
     return 0;
@@ -563,7 +702,7 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     NEED(aln_w, "adapter.ln.w", da); NEED(aln_b, "adapter.ln.b", da);
     NEED(ao_w, "adapter.out.w", (size_t)Q * da); NEED(ao_b, "adapter.out.b", Q);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, A, aln_w, aln_b, Cc, rows, da, 1e-5f,
-                       (const int*)k->d_lens, T);
+                       (const int*)k->d_lens, T, (long)da);
     gemm_f32(st, false, Cc, ao_w, Bb, rows, Q, da, da, da, Q, ao_b);
     // C3: upsample ConvTranspose1d(k = s = up): GEMM to [rows][up*dd] == token-major [rows*up][dd]
     const int up = c.up_stride, T4 = T * up, rows4 = B * T4;
@@ -580,7 +719,7 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     }
     NEED(dln_w, "dec.ln.w", dd); NEED(dln_b, "dec.ln.b", dd);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows4 + 3) / 4), dim3(256), 0, st, A, dln_w, dln_b, Cc, rows4, dd, 1e-5f,
-                       (const int*)k->d_lens4, T4);
+                       (const int*)k->d_lens4, T4, (long)dd);
     NEED(dc1_w, "dec.deconv1.w", (size_t)3 * dd * dd); NEED(dc1_b, "dec.deconv1.b", dd);
     NEED(dc2_w, "dec.deconv2.w", (size_t)3 * c.mel_bins * dd); NEED(dc2_b, "dec.deconv2.b", c.mel_bins);
     gemm_f32(st, false, Cc, dc1_w, Bb, rows4, 3 * dd, dd, dd, dd, 3 * dd);
@@ -595,7 +734,7 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     hipLaunchKernelGGL(im2col7_kernel, dim3(T8, B), dim3(256), 0, st, Cc, Bb, T8, mel);
     gemm_f32(st, false, Bb, ve_w, D, rows8, vd, 7 * mel, 7 * mel, 7 * mel, vd, ve_b);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, D, vn_w, vn_b, A, rows8, vd, 1e-6f,
-                       (const int*)nullptr, T8);
+                       (const int*)nullptr, T8, (long)vd);
     for (int n = 0; n < c.voc_layers; ++n) {
         const std::string p = "voc.blocks." + std::to_string(n) + ".";
         NEED(dw_w, p + "dw.w", (size_t)7 * vd); NEED(dw_b, p + "dw.b", vd);
@@ -610,7 +749,7 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     }
     NEED(fl_w, "voc.final_ln.w", vd); NEED(fl_b, "voc.final_ln.b", vd);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, fl_w, fl_b, Cc, rows8, vd, 1e-6f,
-                       (const int*)nullptr, T8);
+                       (const int*)nullptr, T8, (long)vd);
     // C6: ISTFT head
     const int nfft = c.n_fft, nb = nfft / 2 + 1, ldsp = (2 * nb + 15) / 16 * 16;
     NEED(hd_w, "voc.head.w", (size_t)2 * nb * vd); NEED(hd_b, "voc.head.b", 2 * nb);
@@ -626,6 +765,139 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     CHK(hipMemcpyAsync(&herr, k->d_err, 4, hipMemcpyDeviceToHost, st));
     CHK(hipStreamSynchronize(st));
     if (herr) { hipMemset(k->d_err, 0, 4); return cfail(MTTS_EINVAL, "code index outside the codebook"); }
+    return MTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Encode: 16 kHz waveform chunk (<= 30 s) -> RVQ codes.  Replaces XY_Tokenizer.inference_tokenize
+// (reference model.py:55-101); the mel front-end runs on the device (the reference bounces the
+// waveform device->host->device through a CPU feature extractor, model.py:66-74).
+// dev_wav f32 [B][nsamp] (zero padded), host_lens int32[B] valid samples; dev_codes int64 [nq][B][Tc]
+// with Tc = mel_frames / (2*down_pool) = 375; host_code_lens int32[B] out.
+// ------------------------------------------------------------------------------------
+static int run_audio_encoder(MttsCodec* k, hipStream_t st, const std::string& p, int B, float* A, float* Bb, float* Cc,
+                             float* D) {
+    const MttsCodecConfig& c = k->c;
+    const int d = c.enc_dim, mel = c.mel_bins, T = c.mel_frames, T2 = T / 2;
+    NEED(c1w, p + "conv1.w", (size_t)d * 3 * mel); NEED(c1b, p + "conv1.b", d);
+    NEED(c2w, p + "conv2.w", (size_t)d * 3 * d); NEED(c2b, p + "conv2.b", d);
+    NEED(pe, "enc.pe", (size_t)c.enc_max_pos * d);
+    hipLaunchKernelGGL(im2col_kernel, dim3(T, B), dim3(256), 0, st, k->melbuf, Bb, T, T, mel, 3, 1, 1);
+    gemm_f32(st, false, Bb, c1w, A, B * T, d, 3 * mel, 3 * mel, 3 * mel, d, c1b, 1);
+    hipLaunchKernelGGL(im2col_kernel, dim3(T2, B), dim3(256), 0, st, A, Bb, T, T2, d, 3, 2, 1);
+    gemm_f32(st, false, Bb, c2w, A, B * T2, d, 3 * d, 3 * d, 3 * d, d, c2b, 1, nullptr, pe, d, T2);   // GELU then + PE[t]
+    for (int n = 0; n < c.enc_layers; ++n) {
+        int r = transformer_layer(k, st, p + "layers." + std::to_string(n) + ".", A, Cc, Bb, D, B, T2, d, c.enc_heads,
+                                  c.enc_ffn, k->d_lens2);
+        if (r) return r;
+    }
+    return 0;
+}
+
+extern "C" int32_t mtts_codec_tokenize(MttsCodec* k, const float* dev_wav, const int32_t* host_lens, int32_t B,
+                                       int32_t nsamp, int64_t* dev_codes, int32_t* host_code_lens, void* stream) {
+    if (!k || !dev_wav || !host_lens || !dev_codes || !host_code_lens || B < 1 || nsamp < 1) return cfail(MTTS_EINVAL, "bad argument");
+    const MttsCodecConfig& c = k->c;
+    const int T = c.mel_frames, hop = c.mel_hop, N = T * hop;
+    if (nsamp > N) return cfail(MTTS_EINVAL, "chunk of %d samples exceeds %d", nsamp, N);
+    if (T % (2 * c.down_pool)) return cfail(MTTS_EINVAL, "mel_frames must divide by 2*down_pool");
+    CHK(hipSetDevice(k->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int Tc = T / (2 * c.down_pool), T2 = T / 2;
+    {
+        int r = ensure_workspace(k, B, std::max(Tc, 1));
+        if (r) return r;
+    }
+    std::vector<int> l2(B), l4(B);
+    for (int b = 0; b < B; ++b) {
+        if (host_lens[b] < 0 || host_lens[b] > nsamp) return cfail(MTTS_EINVAL, "length %d out of range", host_lens[b]);
+        const int mel_len = (host_lens[b] + hop - 1) / hop;       // attention_mask[:, ::hop].sum()
+        l2[b] = mel_len / 2;
+        l4[b] = l2[b] / c.down_pool;
+        host_code_lens[b] = l4[b];
+    }
+    CHK(hipMemcpyAsync(k->d_lens2, l2.data(), B * 4, hipMemcpyHostToDevice, st));
+    CHK(hipMemcpyAsync(k->d_lens4, l4.data(), B * 4, hipMemcpyHostToDevice, st));
+    float *A = k->bufA, *Bb = k->bufB, *Cc = k->bufC, *D = k->bufD, *E = k->bufE;
+    const int nfft = c.mel_n_fft, nb = nfft / 2 + 1, ldri = (2 * nb + 15) / 16 * 16, ldp = (nb + 15) / 16 * 16;
+    const int mel = c.mel_bins, d = c.enc_dim;
+    NEED(mwin, "mel.window", nfft); NEED(dft, "mel.dft", (size_t)nfft * ldri); NEED(fb, "mel.fb", (size_t)ldp * mel);
+    // log-mel (feature_extractor.py:78-104)
+    hipLaunchKernelGGL(mel_frames_kernel, dim3(T, B), dim3(256), 0, st, dev_wav, mwin, Bb, nsamp, N, T, nfft, hop);
+    gemm_f32(st, true, Bb, dft, Cc, B * T, ldri, nfft, nfft, ldri, ldri);
+    hipLaunchKernelGGL(power_kernel, dim3(B * T), dim3(256), 0, st, Cc, Bb, nb, ldri, ldp);
+    gemm_f32(st, true, Bb, fb, k->melbuf, B * T, mel, ldp, ldp, mel, mel);
+    hipLaunchKernelGGL(logmel_max_kernel, dim3(B), dim3(256), 0, st, k->melbuf, k->melmax, (long)T * mel);
+    hipLaunchKernelGGL(logmel_norm_kernel, dim3((unsigned)(((long)B * T * mel + 255) / 256)), dim3(256), 0, st, k->melbuf,
+                       k->melmax, (long)T * mel, (long)B * T * mel);
+    const int rows2 = B * T2;
+    NEED(pe, "enc.pe", (size_t)c.enc_max_pos * d);
+    // semantic encoder -> semantic adapter -> E[:, 0:d]
+    {
+        int r = run_audio_encoder(k, st, "sem.", B, A, Bb, Cc, D);
+        if (r) return r;
+        NEED(lw, "sem.ln.w", d); NEED(lb, "sem.ln.b", d);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows2 + 3) / 4), dim3(256), 0, st, A, lw, lb, Cc, rows2, d, 1e-5f,
+                           (const int*)k->d_lens2, T2, (long)d);
+        hipLaunchKernelGGL(add_pe_kernel, dim3((unsigned)(((long)rows2 * d + 255) / 256)), dim3(256), 0, st, Cc, pe,
+                           (long)rows2 * d, T2, d);
+        for (int n = 0; n < c.sem_adapter_layers; ++n) {
+            r = transformer_layer(k, st, "semad.layers." + std::to_string(n) + ".", Cc, A, Bb, D, B, T2, d, c.enc_heads,
+                                  c.enc_ffn, k->d_lens2);
+            if (r) return r;
+        }
+        NEED(aw, "semad.ln.w", d); NEED(ab, "semad.ln.b", d);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows2 + 3) / 4), dim3(256), 0, st, Cc, aw, ab, E, rows2, d, 1e-5f,
+                           (const int*)k->d_lens2, T2, (long)2 * d);
+    }
+    // acoustic encoder -> E[:, d:2d]
+    {
+        int r = run_audio_encoder(k, st, "aco.", B, A, Bb, Cc, D);
+        if (r) return r;
+        NEED(lw, "aco.ln.w", d); NEED(lb, "aco.ln.b", d);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows2 + 3) / 4), dim3(256), 0, st, A, lw, lb, E + d, rows2, d, 1e-5f,
+                           (const int*)k->d_lens2, T2, (long)2 * d);
+    }
+    // pre_rvq_adapter
+    {
+        NEED(pw, "prervq.proj.w", (size_t)d * 2 * d); NEED(pb, "prervq.proj.b", d);
+        gemm_f32(st, false, E, pw, A, rows2, d, 2 * d, 2 * d, 2 * d, d, pb, 0, nullptr, pe, d, T2);
+        for (int n = 0; n < c.pre_rvq_layers; ++n) {
+            int r = transformer_layer(k, st, "prervq.layers." + std::to_string(n) + ".", A, Cc, Bb, D, B, T2, d, c.enc_heads,
+                                      c.enc_ffn, k->d_lens2);
+            if (r) return r;
+        }
+        NEED(lw, "prervq.ln.w", d); NEED(lb, "prervq.ln.b", d);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows2 + 3) / 4), dim3(256), 0, st, A, lw, lb, Cc, rows2, d, 1e-5f,
+                           (const int*)k->d_lens2, T2, (long)d);
+    }
+    // ResidualDownConv (modules.py:452-477): rows of P consecutive frames
+    const int P = c.down_pool, di = d * P, rows4 = B * Tc;
+    {
+        NEED(gw, "down.gate.w", (size_t)di * di); NEED(uw, "down.up.w", (size_t)di * di); NEED(dw, "down.down.w", (size_t)di * di);
+        NEED(lw, "down.ln.w", di); NEED(lb, "down.ln.b", di);
+        gemm_f32(st, false, Cc, gw, A, rows4, di, di, di, di, di);
+        gemm_f32(st, false, Cc, uw, Bb, rows4, di, di, di, di, di);
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)(((long)rows4 * di + 255) / 256)), dim3(256), 0, st, A, Bb,
+                           (long)rows4 * di);
+        gemm_f32(st, false, A, dw, D, rows4, di, di, di, di, di, nullptr, 0, nullptr, Cc, di);
+        hipLaunchKernelGGL(layernorm_wide_kernel, dim3(rows4), dim3(256), 0, st, D, lw, lb, A, di, 1e-5f);
+    }
+    // ResidualVQ.forward, eval branch
+    {
+        const int R = c.rvq_dim, K = c.codebook_size;
+        NEED(iw, "rvq.in.w", (size_t)R * di); NEED(ib, "rvq.in.b", R);
+        gemm_f32(st, false, A, iw, Bb, rows4, R, di, di, di, R, ib);          // residual lives in Bb
+        for (int q = 0; q < c.nq; ++q) {
+            NEED(cb, "rvq.codebook." + std::to_string(q), (size_t)K * R);
+            NEED(cc, "rvq.cc." + std::to_string(q), K);
+            gemm_f32(st, false, Bb, cb, Cc, rows4, K, R, R, R, K);
+            hipLaunchKernelGGL(vq_argmin_update_kernel, dim3(rows4), dim3(256), 0, st, Cc, cb, cc, Bb,
+                               dev_codes + (long)q * rows4, (const int*)k->d_lens4, Tc, K, R);
+        }
+    }
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(st));
     return MTTS_OK;
 }
 

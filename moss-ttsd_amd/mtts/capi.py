@@ -27,7 +27,9 @@ class MttsCodecConfig(C.Structure):
         "nq", "codebook_size", "rvq_dim", "quant_out_dim",
         "adapter_layers", "adapter_dim", "adapter_heads", "adapter_ffn", "adapter_max_pos", "up_stride",
         "dec_layers", "dec_dim", "dec_heads", "dec_ffn", "dec_max_pos", "mel_bins",
-        "voc_dim", "voc_inter", "voc_layers", "n_fft", "hop")]
+        "voc_dim", "voc_inter", "voc_layers", "n_fft", "hop",
+        "mel_n_fft", "mel_hop", "mel_frames", "enc_layers", "enc_dim", "enc_heads", "enc_ffn", "enc_max_pos",
+        "sem_adapter_layers", "pre_rvq_layers", "down_pool")]
 
 
 class MttsError(RuntimeError):
@@ -66,6 +68,7 @@ _SIGS = {
     "mtts_codec_destroy": (C.c_int32, [C.c_void_p]),
     "mtts_codec_bind": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mtts_codec_detokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_codec_tokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_k_gemm_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),
 }

@@ -46,6 +46,86 @@ def istft_basis(n_fft):
     return torch.from_numpy(out)
 
 
+def mel_filter_bank_slaney(n_freq, n_mels, sr, fmin, fmax):
+    """transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney") (third-party), which the
+    reference's MelFeatureExtractor uses (nn/feature_extractor.py:46-54): triangular filters on the slaney
+    mel scale, area-normalised.  -> [n_freq, n_mels] fp32."""
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+    fft_freqs = np.linspace(0, sr // 2, n_freq)
+    filt = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(filt)
+    slopes = filt[None, :] - fft_freqs[:, None]
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / fdiff[:-1], slopes[:, 2:] / fdiff[1:]))
+    fb *= (2.0 / (filt[2:n_mels + 2] - filt[:n_mels]))[None, :]
+    return fb.astype(np.float32)
+
+
+def encoder_role_tensors(cfg, sd):
+    """Encode-side roles."""
+    t = lambda k: (torch.from_numpy(sd[k]) if isinstance(sd[k], np.ndarray) else sd[k]).detach().float().cpu()
+    r = {}
+    n_fft = cfg["mel_n_fft"]
+    nb = n_fft // 2 + 1
+    ldri, ldp = (2 * nb + 15) // 16 * 16, (nb + 15) // 16 * 16
+    n = np.arange(n_fft, dtype=np.float64)[:, None]
+    kk = np.arange(nb, dtype=np.float64)[None, :]
+    dft = np.zeros((n_fft, ldri), dtype=np.float32)
+    dft[:, :nb] = np.cos(2 * np.pi * n * kk / n_fft)
+    dft[:, nb:2 * nb] = -np.sin(2 * np.pi * n * kk / n_fft)
+    r["mel.dft"] = torch.from_numpy(dft)
+    fb = np.zeros((ldp, cfg["mel_bins"]), dtype=np.float32)
+    fb[:nb] = mel_filter_bank_slaney(nb, cfg["mel_bins"], cfg["input_sample_rate"], 0.0, cfg["input_sample_rate"] / 2)
+    r["mel.fb"] = torch.from_numpy(fb)
+    r["mel.window"] = torch.hann_window(n_fft)
+    r["enc.pe"] = sinusoids(cfg["enc_max_pos"], cfg["enc_dim"]).float()
+    d = cfg["enc_dim"]
+
+    def tlayers(src, dst, n_layers):
+        for i in range(n_layers):
+            s, o = f"{src}.layers.{i}.", f"{dst}.layers.{i}."
+            r[o + "qkv.w"] = torch.cat([t(s + "self_attn.q_proj.weight"), t(s + "self_attn.k_proj.weight"),
+                                        t(s + "self_attn.v_proj.weight")], 0).contiguous()
+            r[o + "qkv.b"] = torch.cat([t(s + "self_attn.q_proj.bias"), torch.zeros(d), t(s + "self_attn.v_proj.bias")])
+            r[o + "o.w"], r[o + "o.b"] = t(s + "self_attn.out_proj.weight"), t(s + "self_attn.out_proj.bias")
+            r[o + "ln1.w"], r[o + "ln1.b"] = t(s + "self_attn_layer_norm.weight"), t(s + "self_attn_layer_norm.bias")
+            r[o + "ln2.w"], r[o + "ln2.b"] = t(s + "final_layer_norm.weight"), t(s + "final_layer_norm.bias")
+            r[o + "fc1.w"], r[o + "fc1.b"] = t(s + "fc1.weight"), t(s + "fc1.bias")
+            r[o + "fc2.w"], r[o + "fc2.b"] = t(s + "fc2.weight"), t(s + "fc2.bias")
+
+    for src, dst in (("semantic_encoder", "sem"), ("acoustic_encoder", "aco")):
+        for cv in ("conv1", "conv2"):
+            w = t(f"{src}.{cv}.weight")                                   # [out, in, 3] -> im2col [out][j*in+c]
+            r[f"{dst}.{cv}.w"] = w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+            r[f"{dst}.{cv}.b"] = t(f"{src}.{cv}.bias")
+        tlayers(src, dst, cfg["enc_layers"])
+        r[f"{dst}.ln.w"], r[f"{dst}.ln.b"] = t(f"{src}.layer_norm.weight"), t(f"{src}.layer_norm.bias")
+    tlayers("semantic_encoder_adapter", "semad", cfg["sem_adapter_layers"])
+    r["semad.ln.w"], r["semad.ln.b"] = t("semantic_encoder_adapter.layer_norm.weight"), t("semantic_encoder_adapter.layer_norm.bias")
+    r["prervq.proj.w"], r["prervq.proj.b"] = t("pre_rvq_adapter.proj.weight"), t("pre_rvq_adapter.proj.bias")
+    tlayers("pre_rvq_adapter", "prervq", cfg["pre_rvq_layers"])
+    r["prervq.ln.w"], r["prervq.ln.b"] = t("pre_rvq_adapter.layer_norm.weight"), t("pre_rvq_adapter.layer_norm.bias")
+    for nm, role in (("gate_proj", "gate"), ("up_proj", "up")):
+        w = t(f"downsample.{nm}.weight")                                  # [out, in, P] -> rows of P frames [out][j*in+c]
+        r[f"down.{role}.w"] = w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+    r["down.down.w"] = t("downsample.down_proj.weight")
+    r["down.ln.w"], r["down.ln.b"] = t("downsample.layer_norm.weight"), t("downsample.layer_norm.bias")
+    g, v = t("quantizer.input_proj.weight_g"), t("quantizer.input_proj.weight_v")
+    nrm = v.double().pow(2).sum(dim=(1, 2), keepdim=True).sqrt().float()
+    r["rvq.in.w"] = (g * v / nrm)[:, :, 0].contiguous()
+    r["rvq.in.b"] = t("quantizer.input_proj.bias")
+    for q in range(cfg["nq"]):
+        cb = t(f"quantizer.quantizers.{q}.codebook")
+        r[f"rvq.cc.{q}"] = cb.pow(2).sum(1)                               # codebook.pow(2).sum(1) (quantizer.py:169)
+    return r
+
+
 def role_tensors(cfg, sd):
     """reference state dict (names of XY_Tokenizer.state_dict()) -> {role: fp32 tensor}.
     Every transformation is a pure re-layout except the weight-norm fold of quantizer.output_proj
@@ -114,7 +194,10 @@ class CodecEngine:
     def __init__(self, cfg: dict, device="cuda:0"):
         if not torch.cuda.is_available():
             raise capi.MttsError("no GPU visible: the mtts codec only runs on MI355X (no CPU fallback)")
-        self.cfg = cfg
+        from . import synth_codec
+        full = synth_codec.codec_config()
+        full.update(cfg)                       # configs written before the encode side existed lack its keys
+        self.cfg = cfg = full
         self.device = torch.device(device)
         self.lib = capi.lib()
         c = MttsCodecConfig()
@@ -134,8 +217,14 @@ class CodecEngine:
         except Exception:
             pass
 
-    def bind_state_dict(self, sd):
-        for role, t in role_tensors(self.cfg, sd).items():
+    def bind_state_dict(self, sd, encoder=None):
+        roles = role_tensors(self.cfg, sd)
+        if encoder is None:
+            encoder = "semantic_encoder.conv1.weight" in sd
+        if encoder:
+            roles.update(encoder_role_tensors(self.cfg, sd))
+        self.has_encoder = bool(encoder)
+        for role, t in roles.items():
             d = t.to(device=self.device, dtype=torch.float32).contiguous()
             _check(self.lib.mtts_codec_bind(self._h, role.encode(), d.data_ptr(), d.numel(), None))
         torch.cuda.synchronize(self.device)
@@ -150,6 +239,52 @@ class CodecEngine:
         torch.cuda.synchronize(self.device)
         _check(self.lib.mtts_codec_detokenize(self._h, codes.data_ptr(), lens_arr, B, T, wav.data_ptr(), None))
         return wav
+
+    def tokenize(self, wav: torch.Tensor, lens):
+        """wav fp32 [B, n<=480000] on device (zero padded), lens -> (codes int64 [nq,B,375], code_lens)."""
+        if not getattr(self, "has_encoder", False):
+            raise capi.MttsError("encoder weights are not bound")
+        B, n = wav.shape
+        wav = wav.to(device=self.device, dtype=torch.float32).contiguous()
+        Tc = self.cfg["mel_frames"] // (2 * self.cfg["down_pool"])
+        codes = torch.zeros(self.cfg["nq"], B, Tc, dtype=torch.int64, device=self.device)
+        lens_arr = (C.c_int32 * B)(*[int(x) for x in lens])
+        out_lens = (C.c_int32 * B)()
+        torch.cuda.synchronize(self.device)
+        _check(self.lib.mtts_codec_tokenize(self._h, wav.data_ptr(), lens_arr, B, n, codes.data_ptr(), out_lens, None))
+        return codes, [int(x) for x in out_lens]
+
+    def encode(self, wav_list, overlap_seconds=10):
+        """XY_Tokenizer.encode (reference model.py:131-192): 30 s windows, stride 30-overlap seconds."""
+        c = self.cfg
+        sr, ds = c["input_sample_rate"], c["encoder_downsample_rate"]
+        chunk, dur = int(30 * sr), int((30 - overlap_seconds) * sr)
+        code_dur = dur // ds
+        B = len(wav_list)
+        lens = [int(len(x)) for x in wav_list]
+        maxlen = max(lens)
+        wav = torch.zeros(B, maxlen, dtype=torch.float32, device=self.device)
+        for i, x in enumerate(wav_list):
+            wav[i, :lens[i]] = torch.as_tensor(x, dtype=torch.float32).to(self.device)
+        lens_t = np.array(lens)
+        outs = []
+        for ch in range((maxlen + dur - 1) // dur):
+            start = ch * dur
+            end = min(start + chunk, maxlen)
+            cl = np.clip(lens_t - start, 0, end - start)
+            if cl.max() == 0:
+                continue
+            codes, clen = self.tokenize(wav[:, start:end], cl.tolist())
+            blk = torch.zeros(c["nq"], B, code_dur, dtype=torch.int64, device=self.device)
+            for b in range(B):
+                v = min(clen[b], code_dur)
+                if v > 0:
+                    blk[:, b, :v] = codes[:, b, :v]
+            outs.append(blk)
+        if not outs:
+            return [torch.zeros(c["nq"], 0, dtype=torch.long, device=self.device) for _ in range(B)]
+        full = torch.cat(outs, dim=-1)
+        return [full[:, i, :lens[i] // ds] for i in range(B)]
 
     def decode(self, codes_list, overlap_seconds=10):
         """XY_Tokenizer.decode (reference model.py:195-256): 30 s windows, keep 30-overlap seconds."""

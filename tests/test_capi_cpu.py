@@ -23,4 +23,4 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(capi.MttsConfig) == 17 * 4
     assert C.sizeof(capi.MttsSamplerCfg) == 6 * 4
-    assert C.sizeof(codec.MttsCodecConfig) == 21 * 4
+    assert C.sizeof(codec.MttsCodecConfig) == 32 * 4

@@ -82,3 +82,37 @@ def test_codec_matches_oracle_full_waveform_and_edges():
     with pytest.raises(capi.MttsError):
         eng.decode([torch.from_numpy(bad[0])])
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["codec_enc_3s", "codec_enc_ragged", "codec_enc_35s"])
+def test_codec_encode_matches_reference_fixture(golden_dir, name):
+    """Exact code ids vs the reference XY_Tokenizer.encode (CPU) on the same synthetic audio."""
+    from mtts.codec import CodecEngine
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth_codec.synth_weights(cfg, int(z["seed"]), encoder=True)
+    wavs = synth_codec.synth_wavs(int(z["seed"]) + 1, list(z["lengths"]))
+    eng = CodecEngine(cfg)
+    eng.bind_state_dict(w)
+    got = [g.cpu().numpy() for g in eng.encode([torch.from_numpy(x) for x in wavs])]
+    eng.close()
+    for i, g in enumerate(got):
+        want = z[f"codes{i}"].astype(np.int64)
+        assert g.shape == want.shape
+        mism = float((g != want).mean())
+        assert mism == 0.0, (name, i, mism)
+
+
+def test_codec_encode_decode_roundtrip_shapes():
+    """encode -> decode round trip keeps the length bookkeeping (1280 in / 1920 out per code)."""
+    from mtts.codec import CodecEngine
+    cfg = synth_codec.reduced(dec_layers=1, voc_layers=1, enc_layers=1)
+    w = synth_codec.synth_weights(cfg, 31, encoder=True)
+    eng = CodecEngine(cfg)
+    eng.bind_state_dict(w)
+    wavs = synth_codec.synth_wavs(32, [16000 * 2 + 123, 1280 * 5])
+    codes = eng.encode([torch.from_numpy(x) for x in wavs])
+    assert [tuple(c.shape) for c in codes] == [(8, (16000 * 2 + 123) // 1280), (8, 5)]
+    out = eng.decode(codes)
+    assert [o.shape[0] for o in out] == [c.shape[1] * 1920 for c in codes]
+    eng.close()

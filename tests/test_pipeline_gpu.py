@@ -23,7 +23,14 @@ class Tok:
 
 def _gp(cfg):
     """generator_params dict (yaml shape) for a reduced-depth codec."""
+    enc = {"encoder_layers": cfg["enc_layers"], "d_model": 768, "encoder_attention_heads": 12, "encoder_ffn_dim": 3072,
+           "max_audio_seconds": 30, "sampling_rate": 16000, "hop_length": 160, "stride_size": 2}
     return {"input_sample_rate": 16000, "output_sample_rate": 24000,
+            "feature_extractor_kwargs": {"n_fft": 400, "hop_length": 160, "nb_max_frames": 3000},
+            "semantic_encoder_kwargs": enc, "acoustic_encoder_kwargs": enc,
+            "semantic_encoder_adapter_kwargs": {"encoder_layers": cfg["sem_adapter_layers"]},
+            "pre_rvq_adapter_kwargs": {"encoder_layers": cfg["pre_rvq_layers"]},
+            "downsample_kwargs": {"avg_pooler": 4},
             "quantizer_kwargs": {"num_quantizers": 8, "codebook_size": 1024, "rvq_dim": 512, "output_dim": 3072},
             "post_rvq_adapter_kwargs": {"encoder_layers": cfg["adapter_layers"], "d_model": 768,
                                         "encoder_attention_heads": 12, "encoder_ffn_dim": 3072, "max_source_positions": 375},
@@ -80,6 +87,32 @@ def test_process_batch_text_only_end_to_end():
     if int(last[0]) != int(last[1]):
         _, res2 = gu.process_batch(items, Tok(), model, Broken(), "cuda", "You are a speech synthesizer.", 0)
         assert res2[0] is None and res2[1] is not None
+
+
+def test_process_batch_voice_clone_prompt():
+    """Prompt audio goes through spt.encode (HIP encoder), its codes are teacher-forced through the
+    delay pattern, and the batch mixes a cloned and a text-only item (ragged left padding)."""
+    import generation_utils as gu
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 104, emb_row_sigma=0.6, speech_boost=4.0, eos_boost=1.0)
+    model = AsteroidTTSInstruct.from_state_dict(cfg, w, GenerationConfig(max_new_tokens=16, eos_token_id=cfg["eos_token_id"]))
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1, enc_layers=1)
+    cw = synth_codec.synth_weights(ccfg, 10, encoder=True)
+    spt = XY_Tokenizer(_gp(ccfg), cw).eval().to("cuda")
+    model = model.eval().to("cuda")
+    wav = torch.from_numpy(synth_codec.synth_wavs(3, [16000 * 2])[0])[None]
+    items = [{"text": "[S1]Cloned voice line.", "prompt_audio": (wav, 16000), "prompt_text": "[S1]reference words"},
+             {"text": "[S2]Plain item."}]
+    texts, results = gu.process_batch(items, Tok(), model, spt, "cuda", "sys", 0)
+    assert texts[0]["original_text"] == "[S1]reference words[S1]Cloned voice line."
+    assert all(r is not None and r["audio_data"].shape[1] % 1920 == 0 for r in results)
+    # the prompt codes the engine was fed are exactly what the codec oracle's encoder produces
+    orc = co.CodecEncodeOracle({**synth_codec.codec_config(), **ccfg}, cw)
+    want = orc.encode([wav[0].numpy()])[0]
+    got = spt.encode([wav[0]])["codes_list"][0].cpu().numpy()
+    assert got.shape == (8, 25) and np.array_equal(got, want)
 
 
 def test_model_requires_gpu_and_bf16():
