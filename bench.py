@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--fake-context", action="store_true",
+                    help="PMC/profiling runs only: jump to the target context with mtts_debug_set_kv_len instead of "
+                         "ramping (cache content is not meaningful; the result is marked invalid)")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +155,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("MTTS_BENCH_BACKEND", "nccl")       # "gloo" only to rehearse N>1 on a 1-GPU box
+        local = local % max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -183,6 +191,9 @@ def main():
     # ramp the KV context (untimed for the headline, reported as ramp_frames_per_s)
     t0 = time.perf_counter()
     done_steps = 0
+    if args.fake_context:
+        eng.debug_set_kv_len(n_real + ramp)
+        done_steps = ramp
     while done_steps < ramp:
         n = min(256, ramp - done_steps)
         eng.step(n)
@@ -202,7 +213,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    assert not fin and st == ramp + W + K, (st, fin)
+    assert not fin and st == (0 if args.fake_context else ramp) + W + K, (st, fin)
     # roofline leg: per-kernel HIP events on the launch stream for a few more steps at the same context
     eng.profile(True)
     eng.step(args.profile_steps)
@@ -232,6 +243,15 @@ def main():
         avg_ms = p["ms"] / max(p["launches"], 1)
         bytes_per_launch = p["bytes"] / max(p["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch from separate --pmc passes (profiles/r01_pmc_attention.json; FETCH_SIZE doubled
+        # per the gfx950 correction).  Measured at B=32, L~4095: only quoted for that workload.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attention.json")))["kernels"]
+            if B == 32 and L == 4096 and not args.layers:
+                traffic = pmc[dom + "<2>"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "audio codec tokens/sec/node (decode, bf16, batch 32 @ 4k ctx)",
             "value": value, "unit": "codec_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -246,7 +266,7 @@ def main():
             "ramp_frames_per_s": B * ramp / t_ramp if ramp else None,
             "prefill_s": t_prefill, "setup_s": time.perf_counter() - t_setup,
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": p["launches"]},
             "kernels": {k: {"avg_ms": v["ms"] / max(v["launches"], 1), "launches": v["launches"],
@@ -255,6 +275,8 @@ def main():
         }
         if args.layers:
             out["invalid"] = "depth overridden with --layers"
+        if args.fake_context:
+            out["invalid"] = "context faked with mtts_debug_set_kv_len (profiling run)"
         if world == 1 and not args.no_codec:
             eng.close()
             out["codec_decode"] = codec_leg(device)

@@ -124,6 +124,11 @@ int32_t mtts_read_logits(MttsEngine* e, uint16_t* host_logits0, uint16_t* host_l
 int32_t mtts_profile_enable(MttsEngine* e, int32_t on);
 int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_t* launches, int64_t* bytes);
 
+/* measurement hooks (bench / profiling only, never on the product path) */
+int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len);
+int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,
+                          int32_t iters, float* avg_us);
+
 /* ---- per-kernel entry points (unit tests; device pointers) ---------------- */
 /* Y[32,N] = X[32,K] * W[N,K]^T, bf16 in, fp32 accumulate, bf16 out. */
 int32_t mtts_k_gemm_bf16(const void* dev_w, const void* dev_x, void* dev_y,

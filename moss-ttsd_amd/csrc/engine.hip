@@ -758,6 +758,24 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     return MTTS_OK;
 }
 
+// Measurement hook (bench/profiling only): pretend every live sequence already holds `kv_len` tokens.
+// The cache content is whatever the pages hold; used to reach a long context without replaying it
+// when collecting PMC counters.
+extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int limit = e->max_pages * MTTS_PAGE - MTTS_PAGE;
+    if (kv_len < 1 || kv_len > limit) return fail(MTTS_EINVAL, "kv_len %d outside 1..%d", kv_len, limit);
+    e->max_steps = std::min(e->max_steps, e->steps_issued + e->max_pages * MTTS_PAGE - kv_len);   // stay inside the pages
+    std::vector<SeqState> ss(MTTS_MAXR);
+    HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
+    for (int b = 0; b < e->B; ++b) { ss[b].kv_len = kv_len; e->n_real[b] = kv_len - e->steps_issued; }
+    e->max_real = kv_len - e->steps_issued;
+    HIPCHK(hipMemcpy(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice));
+    return MTTS_OK;
+}
+
 // Tuning hook (not part of the product path): average time of one skinny-GEMM launch over `copies`
 // distinct weight buffers (so that no launch finds its weights in L2 / Infinity Cache).
 extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,

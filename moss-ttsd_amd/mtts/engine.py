@@ -147,6 +147,9 @@ class Engine:
         f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
         return f(l0), f(l17)
 
+    def debug_set_kv_len(self, n):
+        capi.check(self.lib.mtts_debug_set_kv_len(self._h, int(n)))
+
     def profile(self, on=True):
         capi.check(self.lib.mtts_profile_enable(self._h, 1 if on else 0))
 

@@ -5,8 +5,6 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "moss-ttsd_amd"))
 from mtts import capi
 lib = capi.lib()
-lib.mtts_k_gemm_bench.restype = C.c_int32
-lib.mtts_k_gemm_bench.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)]
 shapes = [("qkv", 4096, 2048, 0), ("o", 2048, 2048, 0), ("gateup", 12288, 2048, 2), ("down", 2048, 6144, 0), ("head0", 152704, 2048, 1)]
 for name, N, K, epi in shapes:
     mb = N * K * 2 / 1e6
