@@ -154,9 +154,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
         backend = os.environ.get("MTTS_BENCH_BACKEND", "nccl")       # "gloo" only to rehearse N>1 on a 1-GPU box
-        local = local % max(torch.cuda.device_count(), 1)
+        if backend != "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
