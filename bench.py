@@ -104,6 +104,39 @@ def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
     return step_time, per_layer, min(t_heads)
 
 
+def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=8):
+    """End-to-end figure: prefill + every decode step run so far + codec decode of ALL the
+    frames this run generated (full-depth XY_Tokenizer decoder, 30 s windows / 20 s stride as the reference)."""
+    import torch
+    from mtts import synth_codec
+    from mtts.codec import CodecEngine
+    gen = eng.read_generated(steps_done)                     # [G,B,8]
+    G = gen.shape[0]
+    n = G - 7
+    codes = np.stack([gen[j:n + j, :, j] for j in range(8)], axis=0)      # un-shift (generation_utils.py:416-425)
+    codes[0] -= 151665
+    codes = np.clip(codes, 0, 1023).transpose(0, 2, 1)                    # [8,B,n]
+    cfg = synth_codec.codec_config()
+    cod = CodecEngine(cfg, device=str(device))
+    cod.bind_state_dict(synth_codec.synth_weights(cfg, 5))
+    t = torch.from_numpy(np.ascontiguousarray(codes)).to(device)
+    cod.detokenize(t[:, :1, :375].contiguous(), [375])                    # warm-up / workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = 0
+    for b0 in range(0, B, windows_per_call):
+        wavs = cod.decode([t[:, b] for b in range(b0, min(B, b0 + windows_per_call))])
+        total += sum(int(w.shape[0]) for w in wavs)
+    torch.cuda.synchronize()
+    t_codec = time.perf_counter() - t0
+    cod.close()
+    audio_s = total / 24000.0
+    wall = t_prefill + t_decode + t_codec
+    return {"prefill_s": t_prefill, "decode_s": t_decode, "codec_s": t_codec, "frames": int(B * n),
+            "audio_seconds": audio_s, "codec_ids_per_s": B * n * 8 / wall, "real_time_factor": audio_s / wall,
+            "note": "decode_s = wall time of every decode step of this run (context ramp + timed steps, incl. host syncs)"}
+
+
 def codec_leg(device, windows=8, T=375, reps=3):
     """Secondary figure (not `value`): full-depth XY_Tokenizer decoder, `windows` 30 s windows per call."""
     import torch
@@ -224,6 +257,8 @@ def main():
         ms, n, by = eng.profile_read(which)
         prof[nm] = dict(ms=ms, launches=n, bytes=by)
     eng.profile(False)
+    t_decode_all = t_ramp + dt
+    steps_all, _ = eng.sync_state()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     units = torch.tensor([float(B * K * 8)], dtype=torch.float64, device=device)
@@ -279,6 +314,8 @@ def main():
         if args.fake_context:
             out["invalid"] = "context faked with mtts_debug_set_kv_len (profiling run)"
         if world == 1 and not args.no_codec:
+            if not args.fake_context:
+                out["end_to_end"] = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all)
             eng.close()
             out["codec_decode"] = codec_leg(device)
         if world == 1 and not args.no_cpu_baseline:
