@@ -48,8 +48,9 @@ struct GemmF32Args {
 
 template <bool B_KN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
-    __shared__ float As[GK][GLD];
-    __shared__ float Ws[GK][GLD];
+    // double-buffered LDS tiles; the next tile is fetched into registers while the current one feeds the MFMAs
+    __shared__ float As[2][GK][GLD];
+    __shared__ float Ws[2][GK][GLD];
     const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
     const float* A = g.A + zo * g.sAo + zi * g.sAi;
     const float* W = g.W + zo * g.sWo + zi * g.sWi;
@@ -64,68 +65,85 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
-        // ---- stage A tile (128 rows x 16 k) transposed into As[k][row]
+    float ra[2][4], rw[2][4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 2, kq = idx & 3;
             const int m = m0 + row, k = k0 + 4 * kq;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[i][j] = 0.f;
             if (m < g.M) {
                 const float* p = A + (long)m * g.lda + k;
-                if (k + 3 < g.K) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                else { for (int j = 0; j < 4; ++j) if (k + j < g.K) v[j] = p[j]; }
+                if (k + 3 < g.K) { const float4 t = *(const float4*)p; ra[i][0] = t.x; ra[i][1] = t.y; ra[i][2] = t.z; ra[i][3] = t.w; }
+                else { for (int j = 0; j < 4; ++j) if (k + j < g.K) ra[i][j] = p[j]; }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[4 * kq + j][row] = v[j];
         }
-        if (!B_KN) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rw[i][j] = 0.f;
+            if (!B_KN) {
                 const int row = idx >> 2, kq = idx & 3;
                 const int n = n0 + row, k = k0 + 4 * kq;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (n < g.N) {
                     const float* p = W + (long)n * g.ldw + k;
-                    if (k + 3 < g.K) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                    else { for (int j = 0; j < 4; ++j) if (k + j < g.K) v[j] = p[j]; }
+                    if (k + 3 < g.K) { const float4 t = *(const float4*)p; rw[i][0] = t.x; rw[i][1] = t.y; rw[i][2] = t.z; rw[i][3] = t.w; }
+                    else { for (int j = 0; j < 4; ++j) if (k + j < g.K) rw[i][j] = p[j]; }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Ws[4 * kq + j][row] = v[j];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;
+            } else {
                 const int kr = idx >> 5, nq = idx & 31;
                 const int k = k0 + kr, n = n0 + 4 * nq;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (k < g.K) {
                     const float* p = W + (long)k * g.ldw + n;
-                    if (n + 3 < g.N) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                    else { for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] = p[j]; }
+                    if (n + 3 < g.N) { const float4 t = *(const float4*)p; rw[i][0] = t.x; rw[i][1] = t.y; rw[i][2] = t.z; rw[i][3] = t.w; }
+                    else { for (int j = 0; j < 4; ++j) if (n + j < g.N) rw[i][j] = p[j]; }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Ws[kr][4 * nq + j] = v[j];
             }
         }
-        __syncthreads();
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, kq = idx & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][4 * kq + j][row] = ra[i][j];
+            if (!B_KN) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ws[buf][4 * kq + j][row] = rw[i][j];
+            } else {
+                const int kr = idx >> 5, nq = idx & 31;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ws[buf][kr][4 * nq + j] = rw[i][j];
+            }
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        const bool more = k0 + GK < g.K;
+        if (more) fetch(k0 + GK);
 #pragma unroll
         for (int ks = 0; ks < GK / 2; ++ks) {
             const int kk = 2 * ks + (lane >> 5);
             float a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kk][wm * 64 + i * 32 + (lane & 31)];
+            for (int i = 0; i < 2; ++i) a[i] = As[cur][kk][wm * 64 + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Ws[kk][wn * 64 + j * 32 + (lane & 31)];
+            for (int j = 0; j < 2; ++j) b[j] = Ws[cur][kk][wn * 64 + j * 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
     // ---- epilogue: D[row m][col n], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
