@@ -137,6 +137,29 @@ def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, wi
             "note": "decode_s = wall time of every decode step of this run (context ramp + timed steps, incl. host syncs)"}
 
 
+def overlapped_leg(cfg, eng, device, ids, mask, max_length, layers, seed):
+    """The same job end to end with the codec decoding finished 30 s windows on a second HIP stream while the
+    decode loop keeps running (mtts/streaming.py)."""
+    import torch
+    from mtts import streaming, synth_codec
+    from mtts.codec import CodecEngine
+    ccfg = synth_codec.codec_config()
+    cod = CodecEngine(ccfg, device=str(device))
+    cod.bind_state_dict(synth_codec.synth_weights(ccfg, 5))
+    cod.detokenize(torch.zeros(8, ids.shape[0], 375, dtype=torch.int64, device=device), [375] * ids.shape[0])   # workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen, wavs = streaming.generate_with_overlapped_decode(eng, cod, ids, mask, max_length, layers=layers,
+                                                          do_samples=[True] * 8, seed=seed)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    cod.close()
+    audio_s = sum(int(w.shape[0]) for w in wavs) / 24000.0
+    frames = int((gen.shape[0] - 7) * gen.shape[1])
+    return {"wall_s": wall, "frames": frames, "audio_seconds": audio_s, "codec_ids_per_s": frames * 8 / wall,
+            "real_time_factor": audio_s / wall}
+
+
 def codec_leg(device, windows=8, T=375, reps=3):
     """Secondary figure (not `value`): full-depth XY_Tokenizer decoder, `windows` 30 s windows per call."""
     import torch
@@ -316,6 +339,7 @@ def main():
         if world == 1 and not args.no_codec:
             if not args.fake_context:
                 out["end_to_end"] = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all)
+                out["end_to_end_overlapped"] = overlapped_leg(cfg, eng, device, ids, mask, T + (L - n_real), layers, 42)
             eng.close()
             out["codec_decode"] = codec_leg(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -119,6 +119,10 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
 int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_steps, int32_t* n_steps);
 /* last forward's logits: bf16 bits, channel 0 [B,vocab_size], channels 1..7 [7,B,speech_vocab_size] */
 int32_t mtts_read_logits(MttsEngine* e, uint16_t* host_logits0, uint16_t* host_logits17, void* stream);
+int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream);
+/* Frames first..first+n-1 as codec codes int64 [8][B][n] on the device (delay pattern undone, generation_utils.py:416-425);
+ * `stream` must be ordered after the steps that produced frame first+n+6. */
+int32_t mtts_export_codes(MttsEngine* e, int32_t first, int32_t n, int64_t* dev_codes, void* stream);
 /* name of / time spent in the dominant decode kernel since the last reset, measured with hipEvents
  * on the launch stream (bench.py's roofline leg). */
 int32_t mtts_profile_enable(MttsEngine* e, int32_t on);
@@ -170,6 +174,11 @@ int32_t mtts_codec_bind(MttsCodec* c, const char* role, const float* dev_f32, in
 /* dev_codes int64 [nq][B][T] (T <= 375), host_lens int32 [B]; dev_wav f32 [B][T*1920]. Synchronous. */
 int32_t mtts_codec_detokenize(MttsCodec* c, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
                               float* dev_wav, void* stream);
+/* Enqueue-only form (overlap with the decode loop on another stream); mtts_codec_check() synchronises and
+ * reports a code index outside the codebook. */
+int32_t mtts_codec_detokenize_async(MttsCodec* c, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
+                                    float* dev_wav, void* stream);
+int32_t mtts_codec_check(MttsCodec* c, void* stream);
 /* Encode one chunk (<= 30 s of 16 kHz audio) per row.  Replaces XY_Tokenizer.inference_tokenize
  * (XY_Tokenizer/xy_tokenizer/model.py:55-101), log-mel included.  dev_wav f32 [B][nsamp] zero padded,
  * host_lens int32 [B]; dev_codes int64 [nq][B][375]; host_code_lens int32 [B] (out).  Synchronous. */

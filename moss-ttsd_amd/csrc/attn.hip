@@ -31,19 +31,22 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     const int len = m.pos + 1;
     const int npages = (len + MTTS_PAGE - 1) / MTTS_PAGE;
     if ((int)blockIdx.x * 4 >= npages) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pg = blockIdx.x * 4 + wave;
+    // K loads first (they only need the page index); q is staged through LDS while they fly
+    u32x4_t kv[16];
+    if (pg < npages) {
+        const int page = page_table[(size_t)m.seq * max_pages + pg];
+        const u32x4_t* kp = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+    }
     for (int i = threadIdx.x; i < G * MTTS_HD / 2; i += 256) {
         int g = i / (MTTS_HD / 2), d2 = i % (MTTS_HD / 2);
         qs[g][d2] = ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G + g) * (MTTS_HD / 2) + d2];
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pg = blockIdx.x * 4 + wave;
     if (pg >= npages) return;
-    const int page = page_table[(size_t)m.seq * max_pages + pg];
-    const u32x4_t* kp = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
-    u32x4_t kv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
     float acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.f;
@@ -100,6 +103,16 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     if (chunk * ATT_PB >= npages) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Lmax = max_pages * MTTS_PAGE;
+    const int sub = lane >> 5, dl = lane & 31;
+    // V loads of this wave's first page go out before the softmax statistics are reduced
+    u32x4_t vv[16];
+    int pg = chunk * ATT_PB + wave * (ATT_PB / 4);
+    if (pg < npages) {
+        const int page = page_table[(size_t)m.seq * max_pages + pg];
+        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+    }
     // row-wide softmax statistics from the per-page (max, sumexp) pairs
     float M[G], S[G];
 #pragma unroll
@@ -119,16 +132,15 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[g][i] = 0.f;
-    const int sub = lane >> 5, dl = lane & 31;
 #pragma unroll 1
-    for (int pp = 0; pp < ATT_PB / 4; ++pp) {
-        const int pg = chunk * ATT_PB + wave * (ATT_PB / 4) + pp;
+    for (int pp = 0; pp < ATT_PB / 4; ++pp, ++pg) {
         if (pg >= npages) break;
-        const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
-        u32x4_t vv[16];
+        if (pp > 0) {
+            const int page = page_table[(size_t)m.seq * max_pages + pg];
+            const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+            for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+        }
         // lane t rounds the probability of token pg*64+t once (bf16, as the reference stores it);
         // the V loop reads pairs back from LDS (same wave: LDS ops are ordered).
         {

@@ -540,6 +540,7 @@ struct MttsCodec {
     float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *bufE = nullptr, *big = nullptr, *scores = nullptr;
     float *melbuf = nullptr, *melmax = nullptr;
     int* d_lens2 = nullptr;
+    std::vector<int> h_lens, h_lens4;
     int64_t* d_codes = nullptr;
     int *d_lens = nullptr, *d_lens4 = nullptr, *d_err = nullptr;
 };
@@ -671,8 +672,39 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
 }
 
 // codes: device int64 [nq][B][T]; host_lens int32[B]; wav: device f32 [B][T*up*2*hop]
+static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
+                            float* dev_wav, void* stream);
+
+// Synchronous form: returns after the waveform is complete and the code indices were validated.
 extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes, const int32_t* host_lens, int32_t B,
                                          int32_t T, float* dev_wav, void* stream) {
+    int r = detokenize_async(k, dev_codes, host_lens, B, T, dev_wav, stream);
+    if (r) return r;
+    int herr = 0;
+    CHK(hipMemcpyAsync(&herr, k->d_err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CHK(hipStreamSynchronize((hipStream_t)stream));
+    if (herr) { hipMemset(k->d_err, 0, 4); return cfail(MTTS_EINVAL, "code index outside the codebook"); }
+    return MTTS_OK;
+}
+
+// Asynchronous form for overlapping the codec with the decode loop on another HIP stream: only enqueues.
+// mtts_codec_check() later synchronises the stream and reports a bad code index.
+extern "C" int32_t mtts_codec_detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_t* host_lens, int32_t B,
+                                               int32_t T, float* dev_wav, void* stream) {
+    return detokenize_async(k, dev_codes, host_lens, B, T, dev_wav, stream);
+}
+extern "C" int32_t mtts_codec_check(MttsCodec* k, void* stream) {
+    if (!k) return cfail(MTTS_EINVAL, "null codec");
+    CHK(hipSetDevice(k->device));
+    int herr = 0;
+    CHK(hipMemcpyAsync(&herr, k->d_err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CHK(hipStreamSynchronize((hipStream_t)stream));
+    if (herr) { hipMemset(k->d_err, 0, 4); return cfail(MTTS_EINVAL, "code index outside the codebook"); }
+    return MTTS_OK;
+}
+
+static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_t* host_lens, int32_t B, int32_t T,
+                            float* dev_wav, void* stream) {
     if (!k || !dev_codes || !host_lens || !dev_wav || B < 1 || T < 1) return cfail(MTTS_EINVAL, "bad argument");
     const MttsCodecConfig& c = k->c;
     if (T > c.adapter_max_pos) return cfail(MTTS_EINVAL, "window of %d codes exceeds adapter_max_pos %d", T, c.adapter_max_pos);
@@ -683,7 +715,11 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
         int r = ensure_workspace(k, B, T);
         if (r) return r;
     }
-    std::vector<int> lens(B), lens4(B);
+    std::vector<int>& lens = k->h_lens;
+    std::vector<int>& lens4 = k->h_lens4;
+    CHK(hipStreamSynchronize(st));        // the previous call's async length upload must be done before the host copy is reused
+    lens.resize(B);
+    lens4.resize(B);
     for (int b = 0; b < B; ++b) {
         if (host_lens[b] < 0 || host_lens[b] > T) return cfail(MTTS_EINVAL, "length %d out of range", host_lens[b]);
         lens[b] = host_lens[b];
@@ -779,10 +815,6 @@ extern "C" int32_t mtts_codec_detokenize(MttsCodec* k, const int64_t* dev_codes,
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((nsamp + 255) / 256), B), dim3(256), 0, st, A, win, dev_wav, T8,
                        nfft, c.hop);
     CHK(hipGetLastError());
-    int herr = 0;
-    CHK(hipMemcpyAsync(&herr, k->d_err, 4, hipMemcpyDeviceToHost, st));
-    CHK(hipStreamSynchronize(st));
-    if (herr) { hipMemset(k->d_err, 0, 4); return cfail(MTTS_EINVAL, "code index outside the codebook"); }
     return MTTS_OK;
 }
 

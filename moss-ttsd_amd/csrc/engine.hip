@@ -60,6 +60,8 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
                    LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
                    hipStream_t st);
 
+void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
+                         hipStream_t st);
 #define ATT_PB 8
 
 // ---- errors -------------------------------------------------------------------
@@ -669,6 +671,33 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
     }
     if (decisions) TRY(read_rows(e, e->d_declog, decisions, steps, &ns));
     *out_len = total;
+    return MTTS_OK;
+}
+
+// Per-sequence loop state (needs_additional_steps, unfinished, tokens in the KV cache) after the steps issued so far.
+int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<SeqState> ss(MTTS_MAXR);
+    HIPCHK(hipMemcpyAsync(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    for (int b = 0; b < e->B; ++b) {
+        if (host_nas) host_nas[b] = ss[b].nas;
+        if (host_unfinished) host_unfinished[b] = ss[b].unfinished;
+        if (host_kv_len) host_kv_len[b] = ss[b].kv_len;
+    }
+    return MTTS_OK;
+}
+
+// Frames first..first+n-1 of every sequence as codec codes int64 [8][B][n] on the device (delay pattern undone,
+// channel-0 offset removed): lets the codec decode windows while the decode loop is still running.  The caller
+// orders `stream` after the steps that produced frame first+n+6 (event / same stream).
+int32_t mtts_export_codes(MttsEngine* e, int32_t first, int32_t n, int64_t* dev_codes, void* stream) {
+    if (!e || !e->began || !dev_codes) return fail(MTTS_ESTATE, "nothing generated");
+    if (first < 0 || n < 1 || first + n + 7 > e->steps_issued) return fail(MTTS_EINVAL, "frames %d..%d need %d issued steps, have %d", first, first + n - 1, first + n + 7, e->steps_issued);
+    HIPCHK(hipSetDevice(e->device));
+    launch_export_codes(e->d_gen, dev_codes, e->B, first, n, e->cfg.speech_range_lo, e->cfg.speech_vocab_size - 2, S(stream));
+    HIPCHK(hipGetLastError());
     return MTTS_OK;
 }
 

@@ -502,3 +502,22 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
     hipLaunchKernelGGL(update_kernel, dim3(1), dim3(MTTS_MAXR), 0, st, decisions, dec_log, forced, tf_tail, gen,
                        cur_tokens, seqs, meta, bitmaps, bm_words, ls, host_ls, eos, spad, sp_lo, sp_hi, max_steps);
 }
+
+// Un-shift the delay pattern on the device (reference generation_utils.py:416-425):
+// codes[c][b][f - first] = gen[f + c][b][c] (- speech offset on channel 0), frames first..first+n-1.
+__global__ void export_codes_kernel(const int32_t* __restrict__ gen, int64_t* __restrict__ codes, int B, int first, int n,
+                                    int speech_offset, int clamp_hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 8 * B * n) return;
+    const int t = i % n, b = (i / n) % B, c = i / (n * B);
+    int v = gen[((size_t)(first + t + c) * MTTS_MAXR + b) * 8 + c];
+    if (c == 0) v -= speech_offset;
+    v = min(max(v, 0), clamp_hi);          // flushed / padded frames carry 1024 or EOS: keep the gather in range
+    codes[i] = v;
+}
+void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
+                         hipStream_t st) {
+    int total = 8 * B * n;
+    hipLaunchKernelGGL(export_codes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, gen, codes, B, first, n,
+                       speech_offset, clamp_hi);
+}

@@ -240,6 +240,19 @@ class CodecEngine:
         _check(self.lib.mtts_codec_detokenize(self._h, codes.data_ptr(), lens_arr, B, T, wav.data_ptr(), None))
         return wav
 
+    def detokenize_async(self, codes: torch.Tensor, lens, stream):
+        """Enqueue-only detokenize on `stream` (torch.cuda.Stream); call check(stream) before reading the result."""
+        nq, B, T = codes.shape
+        assert codes.is_contiguous() and codes.dtype == torch.int64
+        wav = torch.empty(B, T * self.cfg["decoder_upsample_rate"], dtype=torch.float32, device=self.device)
+        lens_arr = (C.c_int32 * B)(*[int(x) for x in lens])
+        _check(self.lib.mtts_codec_detokenize_async(self._h, codes.data_ptr(), lens_arr, B, T, wav.data_ptr(),
+                                                    C.c_void_p(stream.cuda_stream)))
+        return wav
+
+    def check(self, stream):
+        _check(self.lib.mtts_codec_check(self._h, C.c_void_p(stream.cuda_stream)))
+
     def tokenize(self, wav: torch.Tensor, lens):
         """wav fp32 [B, n<=480000] on device (zero padded), lens -> (codes int64 [nq,B,375], code_lens)."""
         if not getattr(self, "has_encoder", False):

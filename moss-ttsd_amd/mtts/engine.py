@@ -147,6 +147,19 @@ class Engine:
         f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
         return f(l0), f(l17)
 
+    def seq_state(self):
+        """-> (needs_additional_steps[B], unfinished[B], kv_len[B]) numpy int32."""
+        a, u, k = (np.zeros(self._B, dtype=np.int32) for _ in range(3))
+        capi.check(self.lib.mtts_read_seq_state(self._h, a.ctypes.data, u.ctypes.data, k.ctypes.data, None))
+        return a, u, k
+
+    def export_codes(self, first, n, stream=None):
+        """Frames first..first+n-1 -> int64 [8,B,n] device tensor, enqueued on `stream` (torch.cuda.Stream or None)."""
+        out = torch.empty(8, self._B, n, dtype=torch.int64, device=self.device)
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        capi.check(self.lib.mtts_export_codes(self._h, int(first), int(n), out.data_ptr(), sp))
+        return out
+
     def debug_set_kv_len(self, n):
         capi.check(self.lib.mtts_debug_set_kv_len(self._h, int(n)))
 

@@ -121,3 +121,37 @@ def test_model_requires_gpu_and_bf16():
     m = AsteroidTTSInstruct.from_state_dict(cfg, {})
     with pytest.raises(RuntimeError):
         m.generate(input_ids=torch.zeros(1, 9, 8, dtype=torch.long), attention_mask=torch.ones(1, 9))
+
+
+def test_overlapped_decode_equals_sequential():
+    """Streaming windows decoded on a side stream during generation == per-sample decode afterwards."""
+    from mtts.engine import Engine
+    from mtts.codec import CodecEngine
+    from mtts import streaming
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 7, emb_row_sigma=0.3, speech_boost=8.0, eos_boost=1.0)
+    eng = Engine(cfg, max_batch=3, max_seq_len=1024)
+    eng.bind_state_dict(w)
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1)
+    cod = CodecEngine(ccfg)
+    cod.bind_state_dict(synth_codec.synth_weights(ccfg, 3))
+    ids, mask = synth.synth_prompts(cfg, 5, 3, 24, 0.0, True)
+    max_length = ids.shape[1] + 700                     # 700+ frames: two full windows + a tail per row
+    layers = [dict(top_k=20, top_p=0.9, temperature=1.0)] * 8
+    gen, wavs = streaming.generate_with_overlapped_decode(eng, cod, ids, mask, max_length, layers=layers,
+                                                          do_samples=[True] * 8, seed=11)
+    lens = streaming.valid_lengths(gen)
+    assert (lens > 2 * 250 + 10).all(), lens
+    # sequential reference: same tokens (same seed), decode each sample on its own after the loop
+    out = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=11)
+    T = ids.shape[1]
+    assert np.array_equal(out[:, T - 7:].transpose(1, 0, 2), gen)
+    speech = ao.unshift_outputs(out, T - 7)
+    last = ao.find_max_valid_positions(speech)
+    for b in range(3):
+        assert int(last[b]) + 1 == int(lens[b])
+        want = cod.decode([torch.from_numpy(speech[b, :last[b] + 1].T.copy())])[0]
+        assert wavs[b].shape == want.shape
+        assert torch.equal(wavs[b], want), float((wavs[b] - want).abs().max())
+    eng.close()
+    cod.close()
