@@ -288,6 +288,7 @@ class AsteroidOracle:
         layers = layers or [{} for _ in range(C)]
         do_samples = do_samples or [False] * C
         logits_log, decisions = [], []
+        self.last_margins = []          # relative top-2 gap of every decision, [steps][B,C]
         step = 0
         first = True
         while True:
@@ -308,12 +309,16 @@ class AsteroidOracle:
             if return_logits:
                 logits_log.append([l.copy() for l in logits])
             nxt = np.zeros((B, C), dtype=np.int64)
+            mg = np.zeros((B, C), dtype=F32)
             for c in range(C):
                 sc = apply_processors(ids[..., c], logits[c], layers[c])
                 if do_samples[c]:
                     nxt[:, c] = sample_from_scores(sc, seed, step, c)
                 else:
                     nxt[:, c] = np.argmax(sc, axis=-1)
+                top2 = np.partition(sc, -2, axis=-1)[:, -2:]
+                mg[:, c] = (top2[:, 1] - top2[:, 0]) / np.maximum(np.abs(top2[:, 1]), F32(1e-6))
+            self.last_margins.append(mg)
             is_speech = (nxt[:, 0] >= lo) & (nxt[:, 0] < hi)
             nas[(~is_speech) & (nas < 0)] = C - 1
             if cur + 1 <= tf_inputs.shape[1]:

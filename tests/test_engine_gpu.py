@@ -215,3 +215,77 @@ def test_engine_rejects_bad_inputs(golden_dir, engines):
     ids[0, -1, 1] = 5000                                   # out-of-range speech token
     with pytest.raises(capi.MttsError):
         eng.generate(ids, mask, int(z["max_length"]))
+
+
+def test_engine_long_run_crosses_kv_pages_vs_oracle(engines):
+    """150 steps on a tiny model: positions cross the 64-token page boundaries twice.  The oracle's own greedy run
+    is replayed through the engine; every decision with a safe margin must be identical."""
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 77, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    eng = _engine_for(engines, cfg, w, "long_run")
+    ids, mask = synth.synth_prompts(cfg, 78, 2, 30, 0.4, True)
+    max_length = ids.shape[1] + 150
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    gold = orc.generate(ids, mask, max_length)
+    margins = np.stack(orc.last_margins)                      # [steps,B,C]
+    T = ids.shape[1]
+    assert gold.shape[1] - (T - 7) >= 150                      # nobody flushed early
+    out, dec = eng.generate(ids, mask, max_length, forced=gold)
+    want = gold[:, T - 7:].transpose(1, 0, 2)
+    assert dec.shape == want.shape
+    free = np.ones_like(margins, dtype=bool)
+    for s in range(7):
+        free[s, :, s + 1:] = False                             # teacher-forced slots
+    safe = free & (margins >= MARGIN_OK)
+    assert safe.sum() > 0.8 * free.sum()
+    bad = np.argwhere(safe & (dec != want))
+    assert len(bad) == 0, bad[:10]
+    assert np.array_equal(dec[~free], want[~free])
+
+
+def _rand_weights_on_gpu(cfg, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    lo, hi = cfg["speech_token_range"]
+    for name, shape, kind in synth.weight_shapes(cfg):
+        if kind == "norm":
+            t = (1.0 + 0.1 * torch.randn(shape, device="cuda", generator=g)).to(torch.bfloat16)
+        else:
+            t = (0.02 * torch.randn(shape, device="cuda", generator=g)).to(torch.bfloat16)
+            if name.endswith("embedding_list.0.weight"):
+                t[lo:hi] *= 8.0
+        yield name, t
+
+
+def test_full_size_batch_and_padding_invariance():
+    """BASELINE dims (ASSUMED 1.7B, 28 layers), batch 32, ragged prompts: size-independent properties.
+    (1) a dialogue's tokens do not depend on which other dialogues share the batch or on its row index;
+    (2) extra left padding changes nothing; (3) the first 7 steps reproduce the delayed prompt tail."""
+    from mtts.engine import Engine
+    cfg = synth.assumed_1p7b()
+    eng = Engine(cfg, max_batch=32, max_seq_len=512)
+    for name, t in _rand_weights_on_gpu(cfg, 5):
+        eng.bind(name, t)
+    ids, mask = synth.synth_prompts(cfg, 9, 32, 72, 0.5, True)
+    T = ids.shape[1]
+    max_length = T + 10
+    full = eng.generate(ids, mask, max_length)                 # greedy
+    assert full.shape == (32, T - 7 + 17, 8)
+    rows = [0, 7, 19, 31]
+    sub = eng.generate(ids[rows], mask[rows], max_length)
+    assert np.array_equal(sub, full[rows])
+    # padding invariance: re-pad the same rows 9 slots further left
+    pad_ids = np.concatenate([np.tile(ids[rows][:, :1] * 0 + np.array([cfg["pad_token_id"]] + [1024] * 7), (1, 9, 1)), ids[rows]], axis=1)
+    pad_mask = np.concatenate([np.zeros((len(rows), 9)), mask[rows]], axis=1)
+    padded = eng.generate(pad_ids, pad_mask, max_length + 9)
+    assert np.array_equal(padded[:, 9:], full[rows])
+    # delayed tail: step s (< 7) copies channels s+1.. from the prompt's last 7 slots
+    for s in range(7):
+        assert np.array_equal(full[:, T - 7 + s, s + 1:], ids[:, T - 7 + s, s + 1:])
+    # sampling: same seed -> same tokens; different seed -> different tokens
+    layers = [dict(top_k=50, top_p=0.95, temperature=1.0)] * 8
+    a = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=3)
+    b = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=3)
+    c = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=4)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    eng.close()
