@@ -155,3 +155,40 @@ def test_overlapped_decode_equals_sequential():
         assert torch.equal(wavs[b], want), float((wavs[b] - want).abs().max())
     eng.close()
     cod.close()
+
+
+def test_from_pretrained_directory_and_large_batch(tmp_path):
+    """Local checkpoint directory (config.json + generation_config.json + safetensors) -> from_pretrained;
+    a batch larger than the engine's 32 rows is served in slices with the reference's finished-row padding."""
+    from safetensors.torch import save_file
+    from modeling_asteroid import AsteroidTTSInstruct
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 55, emb_row_sigma=0.6, speech_boost=3.3, eos_boost=3.3)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    hf_cfg = dict(cfg)
+    hf_cfg["rope_parameters"] = {"rope_theta": cfg["rope_theta"], "rope_type": "default"}
+    hf_cfg.pop("rope_theta")
+    (d / "config.json").write_text(json.dumps(hf_cfg))
+    (d / "generation_config.json").write_text(json.dumps({"max_new_tokens": 12, "eos_token_id": cfg["eos_token_id"],
+                                                          "do_samples": [False] * 8, "layers": [{}] * 8}))
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in w.items()}
+    sd["lm_heads.0.weight"] = sd["model.embedding_list.0.weight"].clone()      # tied duplicates are ignored
+    save_file(sd, str(d / "model.safetensors"))
+    model = AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.bfloat16, attn_implementation="sdpa").eval().to("cuda")
+    assert model.config.rope_theta == cfg["rope_theta"] and model.config.head_dim == 128
+    ids, mask = synth.synth_prompts(cfg, 56, 40, 20, 0.3, True)
+    out = model.generate(input_ids=torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda())
+    assert out.is_cuda and out.shape[0] == 40 and out.shape[2] == 8
+    T = ids.shape[1]
+    a = model.generate(input_ids=torch.from_numpy(ids[:32]), attention_mask=torch.from_numpy(mask[:32])).numpy()
+    b = model.generate(input_ids=torch.from_numpy(ids[32:]), attention_mask=torch.from_numpy(mask[32:])).numpy()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:32, :a.shape[1]], a) and np.array_equal(o[32:, :b.shape[1]], b)
+    # rows of the shorter slice are padded the way finished rows are: (eos, 1024 x 7)
+    if a.shape[1] != b.shape[1]:
+        short = slice(0, 32) if a.shape[1] < b.shape[1] else slice(32, 40)
+        n = min(a.shape[1], b.shape[1])
+        assert (o[short, n:, 0] == cfg["eos_token_id"]).all() and (o[short, n:, 1:] == 1024).all()
+    with pytest.raises(NotImplementedError):
+        AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.float16)
