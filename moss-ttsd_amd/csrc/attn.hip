@@ -199,7 +199,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
         const float* p = opart + ((size_t)r * nq + h) * nchunks_max * MTTS_HD + d;
         for (int c = 0; c < nch; ++c) s += p[(size_t)c * MTTS_HD];
     }
-    out_packed[xpack_off(r, h * MTTS_HD + d)] = f2bf(s);
+    out_packed[xpack_off(r, h * MTTS_HD + d, nq * MTTS_HD)] = f2bf(s);
 }
 
 template <int G>

@@ -11,7 +11,8 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 #define MTTS_WAVE 64
-#define MTTS_MAXR 32          // rows (sequences or prefill tokens) per forward pass = one MFMA N-tile
+#define MTTS_MAXR 32          // rows per MFMA N-tile (one activation fragment tile)
+#define MTTS_RCAP 128         // rows (sequences or prefill tokens) per forward pass: up to 4 tiles share one weight stream
 #define MTTS_PAGE 64          // tokens per KV page
 #define MTTS_HD 128           // head_dim the kernels are written for
 
@@ -50,8 +51,9 @@ __device__ __forceinline__ float wave_max(float v) {
 __host__ __device__ __forceinline__ size_t wpack_off(int n, int k, int KT) {
     return ((((size_t)(n >> 5) * KT + (k >> 4)) * 64) + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
 }
-__host__ __device__ __forceinline__ size_t xpack_off(int r, int k) {
-    return (((size_t)(k >> 4) * 64) + r + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+// activations: [row tile r/32][k/16][lane][8]; K = row length of the matrix
+__host__ __device__ __forceinline__ size_t xpack_off(int r, int k, int K) {
+    return (size_t)(r >> 5) * 32 * K + (((size_t)(k >> 4) * 64) + (r & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
 }
 
 // Per-row metadata of one forward pass (R <= 32 rows).

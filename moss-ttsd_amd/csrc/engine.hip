@@ -24,10 +24,10 @@ struct GemmPlan { int waves, ksplit, kt_per_split, kt_per_wave; };
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU = 2 };
 GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit);
 GemmPlan mtts_plan_gemm_forced(int Npad, int K, int ksplit, int waves);
-void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                  float* partial, uint16_t* out, hipStream_t st);
 void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st);
-void launch_pack_rows(const void* src, void* dst, int R, int K, hipStream_t st);
+void launch_pack_rows(const void* src, void* dst, int R, int K, int tiles, hipStream_t st);
 void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st);
 void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
                        void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st);
@@ -184,7 +184,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     if (c->num_attention_heads % c->num_key_value_heads) return fail(MTTS_EINVAL, "bad GQA ratio");
     int G = c->num_attention_heads / c->num_key_value_heads;
     if (G != 1 && G != 2 && G != 4) return fail(MTTS_EINVAL, "GQA group %d not built (1,2,4)", G);
-    if (c->max_batch < 1 || c->max_batch > MTTS_MAXR) return fail(MTTS_EINVAL, "max_batch must be 1..32");
+    if (c->max_batch < 1 || c->max_batch > MTTS_RCAP) return fail(MTTS_EINVAL, "max_batch must be 1..128");
     if (c->vocab_size <= 152694 || c->speech_vocab_size <= 1024)
         return fail(MTTS_EINVAL, "vocab too small for the reference's hard-coded mask ids 152694 / 1024");
     HIPCHK(hipSetDevice(device));
@@ -225,16 +225,16 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
     size_t pmax = std::max({(size_t)e->p_qkv.ksplit * e->qkv_rows, (size_t)e->p_o.ksplit * round_up(H, 32),
                             (size_t)e->p_d.ksplit * round_up(H, 32)});
-    TRY(dalloc(&e->partial, pmax * MTTS_MAXR));
-    TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_MAXR * H));
-    TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_MAXR * H));
-    TRY(dalloc((uint16_t**)&e->xh, (size_t)MTTS_MAXR * H));
-    TRY(dalloc((uint16_t**)&e->hlast, (size_t)MTTS_MAXR * H));
-    TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_MAXR * e->nq * MTTS_HD));
-    TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_MAXR * I));
-    TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_MAXR * e->nq * MTTS_HD));
-    TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_MAXR * e->V0));
-    TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
+    TRY(dalloc(&e->partial, pmax * MTTS_RCAP));
+    TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_RCAP * H));
+    TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_RCAP * H));
+    TRY(dalloc((uint16_t**)&e->xh, (size_t)MTTS_RCAP * H));
+    TRY(dalloc((uint16_t**)&e->hlast, (size_t)MTTS_RCAP * H));
+    TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_RCAP * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_RCAP * I));
+    TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_RCAP * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
+    TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
     // KV pool
     e->max_pages = (c->max_seq_len + MTTS_PAGE - 1) / MTTS_PAGE + 1;
     e->total_pages = e->max_pages * c->max_batch;
@@ -244,22 +244,22 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
     TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
-    TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_MAXR * e->nq * e->max_pages * MTTS_PAGE));
-    TRY(dalloc(&e->stats, (size_t)MTTS_MAXR * e->nq * e->max_pages * 2));
-    TRY(dalloc(&e->opart, (size_t)MTTS_MAXR * e->nq * e->nchunks_max * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_RCAP * e->nq * e->max_pages * MTTS_PAGE));
+    TRY(dalloc(&e->stats, (size_t)MTTS_RCAP * e->nq * e->max_pages * 2));
+    TRY(dalloc(&e->opart, (size_t)MTTS_RCAP * e->nq * e->nchunks_max * MTTS_HD));
     // state
-    TRY(dalloc(&e->d_seqs, MTTS_MAXR));
-    TRY(dalloc(&e->d_meta, MTTS_MAXR));
+    TRY(dalloc(&e->d_seqs, MTTS_RCAP));
+    TRY(dalloc(&e->d_meta, MTTS_RCAP));
     TRY(dalloc(&e->d_ls, 1));
     HIPCHK(hipHostMalloc((void**)&e->h_ls, sizeof(LoopState)));
     memset(e->h_ls, 0, sizeof(LoopState));
-    TRY(dalloc(&e->d_decisions, MTTS_MAXR * 8));
-    TRY(dalloc(&e->d_cur, MTTS_MAXR * 8));
-    TRY(dalloc(&e->d_tf, MTTS_MAXR * 7 * 8));
+    TRY(dalloc(&e->d_decisions, MTTS_RCAP * 8));
+    TRY(dalloc(&e->d_cur, MTTS_RCAP * 8));
+    TRY(dalloc(&e->d_tf, MTTS_RCAP * 7 * 8));
     e->bm_words = (e->V0 + 31) / 32;
-    TRY(dalloc(&e->d_bitmaps, (size_t)MTTS_MAXR * 8 * e->bm_words));
+    TRY(dalloc(&e->d_bitmaps, (size_t)MTTS_RCAP * 8 * e->bm_words));
     TRY(dalloc(&e->d_scfg, 8));
-    TRY(alloc_scratch(e->sscr, MTTS_MAXR));
+    TRY(alloc_scratch(e->sscr, MTTS_RCAP));
     *out = e;
     return MTTS_OK;
 }
@@ -399,12 +399,13 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     const float eps = e->cfg.rms_norm_eps;
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
     const int Hp = round_up(H, 32);
+    const int mb = (R + 31) / 32;                    // activation row tiles sharing each weight stream
     launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, done, st);
     for (int n = 0; n < e->L; ++n) {
         Layer& l = e->layers[n];
         uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
         uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
-        launch_gemm(EPI_PARTIAL, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
+        launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
                         kc, vc, e->d_page_table, e->max_pages, R, nq, nkv, eps, done, st);
         for (int phase = 1; phase <= 3; ++phase) {
@@ -419,10 +420,10 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
             e->prof_bytes[PROF_SCORES] += kv_tokens_hint * nkv * MTTS_HD * 2;
             e->prof_bytes[PROF_PV] += kv_tokens_hint * nkv * MTTS_HD * 2;
         }
-        launch_gemm(EPI_PARTIAL, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
+        launch_gemm(EPI_PARTIAL, mb, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
         launch_resid_norm(e->partial, e->p_o.ksplit, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, done, st);
-        launch_gemm(EPI_SILU, e->p_gu, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
-        launch_gemm(EPI_PARTIAL, e->p_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
+        launch_gemm(EPI_SILU, mb, e->p_gu, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
+        launch_gemm(EPI_PARTIAL, mb, e->p_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
         const bool lastl = (n == e->L - 1);
         const void* nw = lastl ? e->final_norm : e->layers[n + 1].ln_in;
         launch_resid_norm(e->partial, e->p_d.ksplit, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps,
@@ -430,12 +431,14 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     }
     if (heads) {
         const void* xin = e->xn;
+        int hmb = mb;
         if (heads == 2) {
-            launch_pack_rows(e->hlast, e->xh, MTTS_MAXR, H, st);
+            hmb = (e->B + 31) / 32;
+            launch_pack_rows(e->hlast, e->xh, e->B, H, hmb, st);
             xin = e->xh;
         }
-        launch_gemm(EPI_BF16, e->p_h0, e->head0, xin, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, st);
-        launch_gemm(EPI_BF16, e->p_h17, e->heads17, xin, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, st);
+        launch_gemm(EPI_BF16, hmb, e->p_h0, e->head0, xin, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, st);
+        launch_gemm(EPI_BF16, hmb, e->p_h17, e->heads17, xin, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, st);
     }
     HIPCHK(hipGetLastError());
     return MTTS_OK;
@@ -482,14 +485,14 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     if (max_steps > e->gen_cap) {
         if (e->d_gen) { hipFree(e->d_gen); hipFree(e->d_declog); hipFree(e->d_forced); }
         e->gen_cap = max_steps;
-        TRY(dalloc(&e->d_gen, (size_t)max_steps * MTTS_MAXR * 8));
-        TRY(dalloc(&e->d_declog, (size_t)max_steps * MTTS_MAXR * 8));
-        TRY(dalloc(&e->d_forced, (size_t)max_steps * MTTS_MAXR * 8, false));
+        TRY(dalloc(&e->d_gen, (size_t)max_steps * MTTS_RCAP * 8));
+        TRY(dalloc(&e->d_declog, (size_t)max_steps * MTTS_RCAP * 8));
+        TRY(dalloc(&e->d_forced, (size_t)max_steps * MTTS_RCAP * 8, false));
     }
     // flattened prefill rows
     size_t Mtot = 0;
     for (int b = 0; b < B; ++b) Mtot += e->n_real[b];
-    size_t Mpad = (Mtot + MTTS_MAXR - 1) / MTTS_MAXR * MTTS_MAXR;
+    size_t Mpad = (Mtot + MTTS_RCAP - 1) / MTTS_RCAP * MTTS_RCAP;
     std::vector<int32_t> toks(Mpad * 8, 0);
     std::vector<RowMeta> metas(Mpad, RowMeta{-1, 0, 0, 0});
     size_t r = 0;
@@ -514,7 +517,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     HIPCHK(hipMemcpyAsync(e->d_pf_meta, metas.data(), Mpad * sizeof(RowMeta), hipMemcpyHostToDevice, st));
     // history bitmaps (HF repetition penalty sees the whole channel incl. pads: modeling_asteroid.py:129)
     {
-        std::vector<uint32_t> bm((size_t)MTTS_MAXR * 8 * e->bm_words, 0u);
+        std::vector<uint32_t> bm((size_t)MTTS_RCAP * 8 * e->bm_words, 0u);
         for (int b = 0; b < B; ++b)
             for (int t = 0; t < base; ++t)
                 for (int c = 0; c < 8; ++c) {
@@ -523,7 +526,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
                 }
         HIPCHK(hipMemcpyAsync(e->d_bitmaps, bm.data(), bm.size() * 4, hipMemcpyHostToDevice, st));
         // teacher-forcing tail tf_inputs[:, base+s, :] for s = 0..6 (modeling_asteroid.py:143-145)
-        std::vector<int32_t> tf((size_t)MTTS_MAXR * 7 * 8, 0);
+        std::vector<int32_t> tf((size_t)MTTS_RCAP * 7 * 8, 0);
         for (int b = 0; b < B; ++b)
             for (int s = 0; s < 7; ++s)
                 for (int c = 0; c < 8; ++c) {
@@ -532,25 +535,25 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
                     tf[((size_t)b * 7 + s) * 8 + c] = (int32_t)tk;
                 }
         HIPCHK(hipMemcpyAsync(e->d_tf, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
-        std::vector<SeqState> ss(MTTS_MAXR, SeqState{-1, 0, 0, 0});
+        std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0});
         for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0};
         HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
         LoopState ls{0, 0, base, max_length, T, B, 0, 0};
         HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
         *e->h_ls = ls;
-        std::vector<RowMeta> dm(MTTS_MAXR, RowMeta{-1, 0, 0, 0});
+        std::vector<RowMeta> dm(MTTS_RCAP, RowMeta{-1, 0, 0, 0});
         HIPCHK(hipMemcpyAsync(e->d_meta, dm.data(), dm.size() * sizeof(RowMeta), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->d_scfg, sampler, 8 * sizeof(MttsSamplerCfg), hipMemcpyHostToDevice, st));
         e->ch0_sampled = sampler[0].do_sample ? 1 : 0;
-        HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)MTTS_MAXR * 2048 * 4, st));
-        HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)MTTS_MAXR * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)MTTS_RCAP * 2048 * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)MTTS_RCAP * 4, st));
         HIPCHK(hipStreamSynchronize(st));   // host vectors above go out of scope
     }
     // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
     const int pages_bound = (e->max_real + MTTS_PAGE - 1) / MTTS_PAGE;
-    for (size_t off = 0; off < Mpad; off += MTTS_MAXR) {
-        bool lastc = off + MTTS_MAXR >= Mpad;
-        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_MAXR, pages_bound, lastc ? 2 : 0, nullptr,
+    for (size_t off = 0; off < Mpad; off += MTTS_RCAP) {
+        bool lastc = off + MTTS_RCAP >= Mpad;
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_RCAP, pages_bound, lastc ? 2 : 0, nullptr,
                          st, 0));
     }
     e->began = true;
@@ -572,7 +575,7 @@ static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
         // rough KV token count for the profile's byte figure: every row at its current length
         int64_t kvtok = 0;
         for (int b = 0; b < e->B; ++b) kvtok += e->n_real[b] + e->steps_issued + 1;
-        TRY(forward_rows(e, e->d_cur, e->d_meta, MTTS_MAXR, pages_bound, 1, &e->d_ls->done, st, kvtok));
+        TRY(forward_rows(e, e->d_cur, e->d_meta, round_up(e->B, 32), pages_bound, 1, &e->d_ls->done, st, kvtok));
         prof_end(e, st, ev);
         e->steps_issued++;
     }
@@ -599,11 +602,11 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
 static int read_rows(MttsEngine* e, const int32_t* d_src, int64_t* host, int capacity_steps, int* n_steps) {
     int steps = e->h_ls->step;
     if (steps > capacity_steps) return fail(MTTS_EINVAL, "output buffer holds %d steps, need %d", capacity_steps, steps);
-    std::vector<int32_t> tmp((size_t)steps * MTTS_MAXR * 8);
+    std::vector<int32_t> tmp((size_t)steps * MTTS_RCAP * 8);
     if (steps) HIPCHK(hipMemcpy(tmp.data(), d_src, tmp.size() * 4, hipMemcpyDeviceToHost));
     for (int s = 0; s < steps; ++s)
         for (int b = 0; b < e->B; ++b)
-            for (int c = 0; c < 8; ++c) host[((size_t)s * e->B + b) * 8 + c] = tmp[((size_t)s * MTTS_MAXR + b) * 8 + c];
+            for (int c = 0; c < 8; ++c) host[((size_t)s * e->B + b) * 8 + c] = tmp[((size_t)s * MTTS_RCAP + b) * 8 + c];
     if (n_steps) *n_steps = steps;
     return MTTS_OK;
 }
@@ -621,7 +624,7 @@ int32_t mtts_read_logits(MttsEngine* e, uint16_t* l0, uint16_t* l17, void* strea
     HIPCHK(hipStreamSynchronize(S(stream)));
     if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 2, hipMemcpyDeviceToHost));
     if (l17) {
-        std::vector<uint16_t> tmp((size_t)MTTS_MAXR * 7 * e->Vs_pad);
+        std::vector<uint16_t> tmp((size_t)MTTS_RCAP * 7 * e->Vs_pad);
         HIPCHK(hipMemcpy(tmp.data(), e->logits17, tmp.size() * 2, hipMemcpyDeviceToHost));
         for (int c = 0; c < 7; ++c)
             for (int b = 0; b < e->B; ++b)
@@ -639,13 +642,13 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
     const int base = e->base_length;
     if (forced) {
         if (!decisions) return fail(MTTS_EINVAL, "forced replay needs host_decisions");
-        std::vector<int32_t> f((size_t)e->max_steps * MTTS_MAXR * 8, -1);
+        std::vector<int32_t> f((size_t)e->max_steps * MTTS_RCAP * 8, -1);
         for (int s = 0; s < e->max_steps && base + s < forced_len; ++s)
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < 8; ++c) {
                     int64_t tk = forced[((size_t)b * forced_len + base + s) * 8 + c];
                     if (tk < 0 || tk >= (c == 0 ? e->V0 : e->Vs)) return fail(MTTS_EINVAL, "forced token %lld out of range on channel %d", (long long)tk, c);
-                    f[((size_t)s * MTTS_MAXR + b) * 8 + c] = (int32_t)tk;
+                    f[((size_t)s * MTTS_RCAP + b) * 8 + c] = (int32_t)tk;
                 }
         HIPCHK(hipMemcpy(e->d_forced, f.data(), f.size() * 4, hipMemcpyHostToDevice));
         e->has_forced = true;
@@ -678,7 +681,7 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
 int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream) {
     if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
     HIPCHK(hipSetDevice(e->device));
-    std::vector<SeqState> ss(MTTS_MAXR);
+    std::vector<SeqState> ss(MTTS_RCAP);
     HIPCHK(hipMemcpyAsync(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost, S(stream)));
     HIPCHK(hipStreamSynchronize(S(stream)));
     for (int b = 0; b < e->B; ++b) {
@@ -730,18 +733,19 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 
 // ---- per-kernel entry points --------------------------------------------------------
 int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream) {
-    if (!w || !x || !y || M < 1 || M > MTTS_MAXR || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=32, K%%16==0");
+    if (!w || !x || !y || M < 1 || M > MTTS_RCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=128, K%%16==0");
     hipStream_t st = S(stream);
     int Npad = round_up(N, 32);
     void *wp = nullptr, *xp = nullptr;
     float* part = nullptr;
     GemmPlan p = mtts_plan_gemm(Npad, K, ksplit);
     TRY(dalloc((uint16_t**)&wp, (size_t)Npad * K));
-    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_MAXR * K));
-    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_MAXR * Npad));
+    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_RCAP * K));
+    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_RCAP * Npad));
     launch_pack_weight(w, wp, N, K, Npad, 1, 0, st);
-    launch_pack_rows(x, xp, M, K, st);
-    launch_gemm(EPI_PARTIAL, p, wp, xp, K, Npad, Npad, part, nullptr, st);
+    const int tiles = (M + 31) / 32;
+    launch_pack_rows(x, xp, M, K, tiles == 3 ? 4 : tiles, st);
+    launch_gemm(EPI_PARTIAL, tiles, p, wp, xp, K, Npad, Npad, part, nullptr, st);
     launch_reduce_partial_bf16(part, y, p.ksplit, Npad, N, M, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -768,9 +772,9 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     TRY(dalloc(&err, 1));
     TRY(dalloc(&dec, (size_t)rows * 8));
     HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
-    if (rows > MTTS_MAXR) return fail(MTTS_EINVAL, "sample: at most 32 rows");
+    if (rows > MTTS_RCAP) return fail(MTTS_EINVAL, "sample: at most 128 rows");
     SampleScratch sc;
-    TRY(alloc_scratch(sc, MTTS_MAXR));
+    TRY(alloc_scratch(sc, MTTS_RCAP));
     launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, sc, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -797,7 +801,7 @@ extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
     const int limit = e->max_pages * MTTS_PAGE - MTTS_PAGE;
     if (kv_len < 1 || kv_len > limit) return fail(MTTS_EINVAL, "kv_len %d outside 1..%d", kv_len, limit);
     e->max_steps = std::min(e->max_steps, e->steps_issued + e->max_pages * MTTS_PAGE - kv_len);   // stay inside the pages
-    std::vector<SeqState> ss(MTTS_MAXR);
+    std::vector<SeqState> ss(MTTS_RCAP);
     HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
     for (int b = 0; b < e->B; ++b) { ss[b].kv_len = kv_len; e->n_real[b] = kv_len - e->steps_issued; }
     e->max_real = kv_len - e->steps_issued;
@@ -815,16 +819,16 @@ extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t 
     for (auto& q : w) { TRY(dalloc(&q, (size_t)N * K, false)); HIPCHK(hipMemset(q, 0x3c, (size_t)N * K * 2)); }
     uint16_t *x = nullptr, *out = nullptr;
     float* part = nullptr;
-    TRY(dalloc(&x, (size_t)MTTS_MAXR * K, false));
-    HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_MAXR * K * 2));
-    TRY(dalloc(&out, (size_t)MTTS_MAXR * N));
-    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_MAXR * N));
+    TRY(dalloc(&x, (size_t)MTTS_RCAP * K, false));
+    HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_RCAP * K * 2));
+    TRY(dalloc(&out, (size_t)MTTS_RCAP * N));
+    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_RCAP * N));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < copies; ++i) launch_gemm(epi, p, w[i], x, K, N, N, part, out, nullptr);
+    for (int i = 0; i < copies; ++i) launch_gemm(epi, 1, p, w[i], x, K, N, N, part, out, nullptr);
     HIPCHK(hipDeviceSynchronize());
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) launch_gemm(epi, p, w[i % copies], x, K, N, N, part, out, nullptr);
+    for (int i = 0; i < iters; ++i) launch_gemm(epi, 1, p, w[i % copies], x, K, N, N, part, out, nullptr);
     hipEventRecord(e1, nullptr);
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;

@@ -14,9 +14,9 @@
 
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU = 2 };
 
-// grid = (N/32, ksplit); block = WAVES*64.
+// grid = (N/32, ksplit); block = WAVES*64.  MB = row tiles (of 32) that share the weight stream.
 // kt_per_split: k-tiles (of 16) per blockIdx.y; kt_per_wave: per wave inside that.
-template <int WAVES, int EPI>
+template <int WAVES, int EPI, int MB>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const u32x4_t* __restrict__ Wp, const u32x4_t* __restrict__ Xp, int KT, int kt_per_split,
     int kt_per_wave, float* __restrict__ partial, uint16_t* __restrict__ out, int Npad, int n_valid) {
@@ -25,65 +25,80 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int kt0 = ks * kt_per_split + wave * kt_per_wave;
     int kt1 = min(min(kt0 + kt_per_wave, (ks + 1) * kt_per_split), KT);
-    f32x16_t acc;
+    f32x16_t acc[MB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
     const u32x4_t* wp = Wp + ((size_t)nt * KT + kt0) * 64 + lane;
     const u32x4_t* xp = Xp + (size_t)kt0 * 64 + lane;
+    const size_t xtile = (size_t)KT * 64;            // one 32-row activation tile, in 16-byte units
+    constexpr int U = (MB == 1) ? 8 : 4;
     int n = kt1 - kt0;
     int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        u32x4_t a[8], b[8];
+    for (; i + U <= n; i += U) {
+        u32x4_t a[U], b[U][MB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
+        for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b[u] = xp[(size_t)(i + u) * 64];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a[u], *(bf16x8_t*)&b[u], acc, 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) b[u][mb] = xp[(size_t)(i + u) * 64 + mb * xtile];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a[u], *(bf16x8_t*)&b[u][mb], acc[mb], 0, 0, 0);
     }
     for (; i < n; ++i) {
         u32x4_t a = __builtin_nontemporal_load(wp + (size_t)i * 64);
-        u32x4_t b = xp[(size_t)i * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a, *(bf16x8_t*)&b, acc, 0, 0, 0);
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-    const int l2 = threadIdx.x & 63;
-    for (int q = threadIdx.x >> 6; q < 4; q += WAVES) {      // q: register quad 4q..4q+3
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float s = red[0][4 * q + j][l2];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += red[w][4 * q + j][l2];
-        v[j] = s;
-    }
-    const int row = l2 & 31;                       // activation row (sequence / token)
-    const int nl = 8 * q + 4 * (l2 >> 5);          // first of 4 consecutive n in the tile
-    const int n0 = nt * 32 + nl;
-    if (EPI == EPI_PARTIAL) {
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(partial + ((size_t)ks * MTTS_MAXR + row) * Npad + n0) = o;
-    } else if (EPI == EPI_BF16) {
-        // row-major [32][n_valid] bf16 (logits): rows are not 8-byte aligned when n_valid is odd
-        uint16_t* o = out + (size_t)row * n_valid + n0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < n_valid) o[j] = f2bf(v[j]);
-    } else {
-        // rows interleaved gate,up,gate,up: SwiGLU (modeling_qwen3.py:81-83) with the
-        // reference's bf16 rounding points: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
-        // Output goes straight into the X-fragment layout of the down projection.
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float g = rbf(v[2 * j]), u = rbf(v[2 * j + 1]);
-            float a = rbf(g / (1.0f + expf(-g)));
-            int idx = (n0 >> 1) + j;
-            out[xpack_off(row, idx)] = f2bf(a * u);
+        for (int mb = 0; mb < MB; ++mb) {
+            u32x4_t b = xp[(size_t)i * 64 + mb * xtile];
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a, *(bf16x8_t*)&b, acc[mb], 0, 0, 0);
         }
     }
+    const int l2 = threadIdx.x & 63;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (mb) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[mb][r];
+        __syncthreads();
+        for (int q = threadIdx.x >> 6; q < 4; q += WAVES) {      // q: register quad 4q..4q+3
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = red[0][4 * q + j][l2];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) s += red[w][4 * q + j][l2];
+                v[j] = s;
+            }
+            const int row = mb * 32 + (l2 & 31);           // activation row (sequence / token)
+            const int nl = 8 * q + 4 * (l2 >> 5);          // first of 4 consecutive n in the tile
+            const int n0 = nt * 32 + nl;
+            if (EPI == EPI_PARTIAL) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(partial + ((size_t)ks * MTTS_RCAP + row) * Npad + n0) = o;
+            } else if (EPI == EPI_BF16) {
+                // row-major [rows][n_valid] bf16 (logits): rows are not 8-byte aligned when n_valid is odd
+                uint16_t* o = out + (size_t)row * n_valid + n0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+            } else {
+                // rows interleaved gate,up,gate,up: SwiGLU (modeling_qwen3.py:81-83) with the
+                // reference's bf16 rounding points: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
+                // Output goes straight into the X-fragment layout of the down projection (K = Npad/2).
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float g = rbf(v[2 * j]), u = rbf(v[2 * j + 1]);
+                    float a = rbf(g / (1.0f + expf(-g)));
+                    int idx = (n0 >> 1) + j;
+                    out[xpack_off(row, idx, Npad >> 1)] = f2bf(a * u);
+                }
+            }
+        }
     }
 }
 
@@ -110,12 +125,14 @@ __global__ void pack_weight_kernel(const uint16_t* __restrict__ src, uint16_t* _
     }
 }
 
-// Row-major activations [R][K] bf16 -> X-fragment layout (rows >= R are zero).
-__global__ void pack_rows_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int R, int K) {
-    int total = (K >> 4) * 64;
+// Row-major activations [R][K] bf16 -> X-fragment layout, `tiles` row tiles (rows >= R are zero).
+__global__ void pack_rows_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int R, int K, int tiles) {
+    int per_tile = (K >> 4) * 64;
+    int total = per_tile * tiles;
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
-        int lane = g & 63, kt = g >> 6;
-        int r = lane & 31, k = kt * 16 + 8 * (lane >> 5);
+        int tile = g / per_tile, gi = g % per_tile;
+        int lane = gi & 63, kt = gi >> 6;
+        int r = tile * 32 + (lane & 31), k = kt * 16 + 8 * (lane >> 5);
         u32x4_t v = {0u, 0u, 0u, 0u};
         if (r < R) v = *(const u32x4_t*)(src + (size_t)r * K + k);
         *(u32x4_t*)(dst + (size_t)g * 8) = v;
@@ -129,7 +146,7 @@ __global__ void reduce_partial_bf16_kernel(const float* __restrict__ partial, ui
     if (idx >= R * n_valid) return;
     int r = idx / n_valid, n = idx % n_valid;
     float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += partial[((size_t)k * MTTS_MAXR + r) * Npad + n];
+    for (int k = 0; k < ksplit; ++k) s += partial[((size_t)k * MTTS_RCAP + r) * Npad + n];
     out[idx] = f2bf(s);
 }
 
@@ -157,14 +174,14 @@ static GemmPlan plan_gemm(int Npad, int K, int want_ksplit) {
     return p;
 }
 
-template <int EPI>
+template <int EPI, int MB>
 static void launch_gemm_epi(const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                             float* partial, uint16_t* out, hipStream_t st) {
     dim3 grid(Npad / 32, p.ksplit);
     int KT = K / 16;
 #define MTTS_GEMM_CASE(WV)                                                                            \
     case WV:                                                                                          \
-        hipLaunchKernelGGL((gemm_skinny_kernel<WV, EPI>), grid, dim3(WV * 64), 0, st,                 \
+        hipLaunchKernelGGL((gemm_skinny_kernel<WV, EPI, MB>), grid, dim3(WV * 64), 0, st,             \
                            (const u32x4_t*)Wp, (const u32x4_t*)Xp, KT, p.kt_per_split, p.kt_per_wave, \
                            partial, out, Npad, n_valid);                                              \
         break;
@@ -177,11 +194,20 @@ static void launch_gemm_epi(const GemmPlan& p, const void* Wp, const void* Xp, i
 #undef MTTS_GEMM_CASE
 }
 
-void launch_gemm(int epi, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+template <int EPI>
+static void launch_gemm_mb(int mb, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                           float* partial, uint16_t* out, hipStream_t st) {
+    if (mb <= 1) launch_gemm_epi<EPI, 1>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else if (mb == 2) launch_gemm_epi<EPI, 2>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else launch_gemm_epi<EPI, 4>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);     // 3 tiles run as 4 (zero tile)
+}
+
+// mb = number of 32-row activation tiles (1..4) that share the weight stream
+void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                  float* partial, uint16_t* out, hipStream_t st) {
-    if (epi == EPI_PARTIAL) launch_gemm_epi<EPI_PARTIAL>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
-    else if (epi == EPI_BF16) launch_gemm_epi<EPI_BF16>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
-    else launch_gemm_epi<EPI_SILU>(p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    if (epi == EPI_PARTIAL) launch_gemm_mb<EPI_PARTIAL>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else if (epi == EPI_BF16) launch_gemm_mb<EPI_BF16>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+    else launch_gemm_mb<EPI_SILU>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
 }
 
 GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit) { return plan_gemm(Npad, K, want_ksplit); }
@@ -202,10 +228,10 @@ void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, rows,
                        cols, rows_pad, row_mul, row_off);
 }
-void launch_pack_rows(const void* src, void* dst, int R, int K, hipStream_t st) {
-    int total = (K / 16) * 64;
+void launch_pack_rows(const void* src, void* dst, int R, int K, int tiles, hipStream_t st) {
+    int total = (K / 16) * 64 * tiles;
     hipLaunchKernelGGL(pack_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint16_t*)src,
-                       (uint16_t*)dst, R, K);
+                       (uint16_t*)dst, R, K, tiles);
 }
 void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st) {
     int total = R * n_valid;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = bf2f(x[(size_t)r * H + i]);
         float y = rbf(bf2f(norm_w[i]) * rbf(v * inv));
-        xn_packed[xpack_off(r, i)] = f2bf(y);
+        xn_packed[xpack_off(r, i, H)] = f2bf(y);
     }
 }
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
             const float* p0 = partial + (size_t)r * Npad + i0;
             float4 a = *(const float4*)p0, b = *(const float4*)(p0 + 4);
             for (int k = 1; k < ksplit; ++k) {
-                const float* pk = partial + ((size_t)k * MTTS_MAXR + r) * Npad + i0;
+                const float* pk = partial + ((size_t)k * MTTS_RCAP + r) * Npad + i0;
                 float4 a2 = *(const float4*)pk, b2 = *(const float4*)(pk + 4);
                 a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
                 b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
             y.y = pack2(bflo(w.y) * rbf(v[c][2] * inv), bfhi(w.y) * rbf(v[c][3] * inv));
             y.z = pack2(bflo(w.z) * rbf(v[c][4] * inv), bfhi(w.z) * rbf(v[c][5] * inv));
             y.w = pack2(bflo(w.w) * rbf(v[c][6] * inv), bfhi(w.w) * rbf(v[c][7] * inv));
-            if (xn_packed) *(u32x4_t*)(xn_packed + xpack_off(r, i0)) = y;
+            if (xn_packed) *(u32x4_t*)(xn_packed + xpack_off(r, i0, H)) = y;
             if (hlast && m.seq >= 0 && m.last) *(u32x4_t*)(hlast + (size_t)m.seq * H + i0) = y;
         }
     }
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     float a = partial[(size_t)r * Npad + col + l];
     float b = partial[(size_t)r * Npad + col + l + 64];
     for (int k = 1; k < ksplit; ++k) {
-        a += partial[((size_t)k * MTTS_MAXR + r) * Npad + col + l];
-        b += partial[((size_t)k * MTTS_MAXR + r) * Npad + col + l + 64];
+        a += partial[((size_t)k * MTTS_RCAP + r) * Npad + col + l];
+        b += partial[((size_t)k * MTTS_RCAP + r) * Npad + col + l + 64];
     }
     a = rbf(a);
     b = rbf(b);

@@ -428,18 +428,18 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
         }
         if (dec_log) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) dec_log[((size_t)step * MTTS_MAXR + b) * 8 + c] = tok[c];
+            for (int c = 0; c < 8; ++c) dec_log[((size_t)step * MTTS_RCAP + b) * 8 + c] = tok[c];
         }
         if (forced) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                int f = forced[((size_t)step * MTTS_MAXR + b) * 8 + c];
+                int f = forced[((size_t)step * MTTS_RCAP + b) * 8 + c];
                 if (f >= 0) tok[c] = f;
             }
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            gen[((size_t)step * MTTS_MAXR + b) * 8 + c] = tok[c];
+            gen[((size_t)step * MTTS_RCAP + b) * 8 + c] = tok[c];
             cur_tokens[b * 8 + c] = tok[c];
             uint32_t* bm = bitmaps + ((size_t)b * 8 + c) * bm_words;
             bm[tok[c] >> 5] |= 1u << (tok[c] & 31);       // history for the repetition penalty
@@ -499,7 +499,7 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
                    LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
                    hipStream_t st) {
-    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(MTTS_MAXR), 0, st, decisions, dec_log, forced, tf_tail, gen,
+    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(MTTS_RCAP), 0, st, decisions, dec_log, forced, tf_tail, gen,
                        cur_tokens, seqs, meta, bitmaps, bm_words, ls, host_ls, eos, spad, sp_lo, sp_hi, max_steps);
 }
 
@@ -510,7 +510,7 @@ __global__ void export_codes_kernel(const int32_t* __restrict__ gen, int64_t* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 8 * B * n) return;
     const int t = i % n, b = (i / n) % B, c = i / (n * B);
-    int v = gen[((size_t)(first + t + c) * MTTS_MAXR + b) * 8 + c];
+    int v = gen[((size_t)(first + t + c) * MTTS_RCAP + b) * 8 + c];
     if (c == 0) v -= speech_offset;
     v = min(max(v, 0), clamp_hi);          // flushed / padded frames carry 1024 or EOS: keep the gather in range
     codes[i] = v;

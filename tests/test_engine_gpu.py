@@ -24,7 +24,8 @@ def _bf16_t(a):
 def test_gemm_kernel_matches_fp32_reference():
     rng = np.random.default_rng(0)
     lib = capi.lib()
-    for (M, N, K, ks) in [(32, 1024, 256, 0), (5, 4096, 2048, 0), (32, 2048, 6144, 4), (17, 1025, 512, 1), (32, 96, 64, 1)]:
+    for (M, N, K, ks) in [(32, 1024, 256, 0), (5, 4096, 2048, 0), (32, 2048, 6144, 4), (17, 1025, 512, 1), (32, 96, 64, 1),
+                          (100, 1024, 512, 0), (128, 2048, 2048, 2), (64, 4096, 256, 1)]:
         w = ao.round_bf16(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
         x = ao.round_bf16(rng.standard_normal((M, K)).astype(np.float32))
         wt, xt = _bf16_t(w), _bf16_t(x)
@@ -289,3 +290,27 @@ def test_full_size_batch_and_padding_invariance():
     c = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=4)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     eng.close()
+
+
+def test_engine_multi_tile_batch_equals_single_tile(engines):
+    """40 dialogues in ONE pass (two 32-row activation tiles share each weight stream) == the same
+    dialogues served 32 + 8: per-row results do not depend on the tiling."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 91, emb_row_sigma=0.6, speech_boost=5.0, eos_boost=5.0)
+    big = Engine(cfg, max_batch=64, max_seq_len=256)
+    big.bind_state_dict(w)
+    ids, mask = synth.synth_prompts(cfg, 92, 40, 26, 0.4, True)
+    max_length = ids.shape[1] + 20
+    one = big.generate(ids, mask, max_length)
+    small = _engine_for(engines, cfg, w, "multi_tile_small")
+    parts = [small.generate(ids[s:s + 4], mask[s:s + 4], max_length) for s in range(0, 40, 4)]
+    for s, p in zip(range(0, 40, 4), parts):
+        n = p.shape[1]
+        assert np.array_equal(one[s:s + 4, :n], p), s
+        assert (one[s:s + 4, n:, 0] == cfg["eos_token_id"]).all()        # finished-row padding beyond their own end
+    layers = [dict(top_k=30, top_p=0.9, temperature=0.9, repetition_penalty=1.1)] * 8
+    a = big.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=5)
+    b = big.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=5)
+    assert np.array_equal(a, b)
+    big.close()
