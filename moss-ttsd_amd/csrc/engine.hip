@@ -44,16 +44,17 @@ int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const 
                 int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, pad; };
 struct LoopState { int32_t step, done, base_length, max_length, tf_len, B, error, pad; };
-struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; };
+struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
 #define SAMP_CAND 4096
 #define SAMP_NS 32
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps,
                    int bm_words, const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions,
-                   int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, hipStream_t st);
+                   int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, int full_cap, hipStream_t st);
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
-                          int32_t* decisions, int32_t* err, const SampleScratch& sc, hipStream_t st);
-static int alloc_scratch(SampleScratch& sc, int rows);
+                          int32_t* decisions, int32_t* err, const SampleScratch& sc, int full_cap, hipStream_t st);
+static int alloc_scratch(SampleScratch& sc, int rows, int vocab);
+static int full_cap_for(int vocab) { int p = 1; while (p < vocab) p <<= 1; return vocab > SAMP_CAND ? p : 0; }
 static void free_scratch(SampleScratch& sc);
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
@@ -162,7 +163,14 @@ static int dalloc(T** p, size_t n, bool zero = true) {
         if (_r) return _r; \
     } while (0)
 
-static int alloc_scratch(SampleScratch& sc, int rows) {
+static int alloc_scratch(SampleScratch& sc, int rows, int vocab) {
+    const int fc = full_cap_for(vocab);
+    sc.full_val = nullptr; sc.full_idx = nullptr;
+    TRY(dalloc(&sc.overflow, (size_t)rows));
+    if (fc) {            // full-vocabulary sort space (sampling without top_k): rows x next_pow2(vocab) pairs
+        TRY(dalloc(&sc.full_val, (size_t)rows * fc, false));
+        TRY(dalloc(&sc.full_idx, (size_t)rows * fc, false));
+    }
     TRY(dalloc(&sc.hist, (size_t)rows * 2048));
     TRY(dalloc(&sc.slice_val, (size_t)rows * SAMP_NS));
     TRY(dalloc(&sc.slice_idx, (size_t)rows * SAMP_NS));
@@ -173,6 +181,8 @@ static int alloc_scratch(SampleScratch& sc, int rows) {
 }
 static void free_scratch(SampleScratch& sc) {
     hipFree(sc.hist); hipFree(sc.slice_val); hipFree(sc.slice_idx); hipFree(sc.cand_val); hipFree(sc.cand_idx); hipFree(sc.cand_n);
+    hipFree(sc.overflow);
+    if (sc.full_val) { hipFree(sc.full_val); hipFree(sc.full_idx); }
 }
 
 int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out) {
@@ -259,7 +269,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->bm_words = (e->V0 + 31) / 32;
     TRY(dalloc(&e->d_bitmaps, (size_t)MTTS_RCAP * 8 * e->bm_words));
     TRY(dalloc(&e->d_scfg, 8));
-    TRY(alloc_scratch(e->sscr, MTTS_RCAP));
+    TRY(alloc_scratch(e->sscr, c->max_batch, e->V0));
     *out = e;
     return MTTS_OK;
 }
@@ -545,8 +555,9 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         HIPCHK(hipMemcpyAsync(e->d_meta, dm.data(), dm.size() * sizeof(RowMeta), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->d_scfg, sampler, 8 * sizeof(MttsSamplerCfg), hipMemcpyHostToDevice, st));
         e->ch0_sampled = sampler[0].do_sample ? 1 : 0;
-        HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)MTTS_RCAP * 2048 * 4, st));
-        HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)MTTS_RCAP * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)e->cfg.max_batch * 2048 * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)e->cfg.max_batch * 4, st));
+        HIPCHK(hipMemsetAsync(e->sscr.overflow, 0, (size_t)e->cfg.max_batch * 4, st));
         HIPCHK(hipStreamSynchronize(st));   // host vectors above go out of scope
     }
     // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
@@ -566,7 +577,7 @@ static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
         hipEvent_t ev = nullptr;
         prof_begin(e, PROF_STEP, st, &ev);
         launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
-                      e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled, st);
+                      e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled, full_cap_for(e->V0), st);
         launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
                       e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, nullptr, e->cfg.eos_token_id,
                       e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, e->max_steps, st);
@@ -774,8 +785,8 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
     if (rows > MTTS_RCAP) return fail(MTTS_EINVAL, "sample: at most 128 rows");
     SampleScratch sc;
-    TRY(alloc_scratch(sc, MTTS_RCAP));
-    launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, sc, st);
+    TRY(alloc_scratch(sc, rows, vocab));
+    launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, sc, full_cap_for(vocab), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     free_scratch(sc);

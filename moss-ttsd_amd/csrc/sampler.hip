@@ -91,7 +91,10 @@ struct SampleScratch {
     int32_t* slice_idx;    // [32][SAMP_NS]
     float* cand_val;       // [32][SAMP_CAND]
     int32_t* cand_idx;     // [32][SAMP_CAND]
-    uint32_t* cand_n;      // [32]
+    uint32_t* cand_n;      // [rows]
+    int32_t* overflow;     // [rows] set by the final kernel when a row needs the full-vocabulary path
+    float* full_val;       // [rows][full_cap]
+    int32_t* full_idx;     // [rows][full_cap]
 };
 
 struct SampleCtx {         // resolved per (row, channel)
@@ -230,23 +233,109 @@ __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
     }
 }
 
-// block-wide exclusive prefix sum of one float per thread (SAMP_T threads); returns (exclusive, total)
-__device__ __forceinline__ float block_excl_scan(float v, float* sh, float& total) {
+// block-wide exclusive prefix sum of one double per thread (NT threads); returns (exclusive, total).
+// Sums run in fp64: a nucleus over the whole 152 k vocabulary has terms of 1e-5 of the total, and the draw must
+// land on the same token as the oracle's fp64 cumulative sum.
+template <int NT>
+__device__ __forceinline__ double block_excl_scan(double v, double* sh, double& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float inc = v;
+    double inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(inc, o, 64);
+        double t = __shfl_up(inc, o, 64);
         if (lane >= o) inc += t;
     }
     __syncthreads();
     if (lane == 63) sh[wid] = inc;
     __syncthreads();
-    float base = 0.f, tot = 0.f;
-    for (int w = 0; w < SAMP_T / 64; ++w) { if (w < wid) base += sh[w]; tot += sh[w]; }
+    double base = 0.0, tot = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { if (w < wid) base += sh[w]; tot += sh[w]; }
     total = tot;
     __syncthreads();
     return base + inc - v;
+}
+
+// Everything after the candidates are known: sort, HF top-k / top-p cuts, Philox draw.
+// val/idx: n candidate (score, id) pairs (LDS for the fast path, global memory for the full-vocabulary path),
+// capacity >= next_pow2(n).  NT threads.  Returns the chosen token in every thread.
+template <int NT>
+__device__ int finish_sample(float* __restrict__ cval, int* __restrict__ cidx, int n, const MttsSamplerCfg& cfg, float smax,
+                             uint32_t step, uint32_t b, uint32_t c, uint64_t seed, double* shd, int* sh_i) {
+    const int tid = threadIdx.x;
+    // bitonic sort of P = next_pow2(n) slots by (score asc, id asc); padding sorts last
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += NT) { cval[i] = INFINITY; cidx[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P; t += NT) {
+                int ixj = t ^ j;
+                if (ixj > t) {
+                    bool up = ((t & kk) == 0);
+                    float a = cval[t], bb = cval[ixj];
+                    int ai = cidx[t], bi2 = cidx[ixj];
+                    bool gt = (a > bb) || (a == bb && ai > bi2);
+                    if (gt == up) { cval[t] = bb; cval[ixj] = a; cidx[t] = bi2; cidx[ixj] = ai; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // top-k (HF TopKLogitsWarper): drop scores < k-th largest; ties with the k-th stay
+    int f0 = 0;
+    if (cfg.top_k > 0 && cfg.top_k < n) {
+        const float thr = cval[n - cfg.top_k];
+        int cnt = 0;
+        for (int i = tid; i < n; i += NT) cnt += (cval[i] < thr) ? 1 : 0;
+        double tot;
+        (void)block_excl_scan<NT>((double)cnt, shd, tot);
+        f0 = (int)tot;
+    }
+    // top-p (HF TopPLogitsWarper): ascending cumulative softmax over the survivors; drop cum <= 1-p,
+    // always keep the last (most probable) one.  Thread t owns a contiguous run of the kept range.
+    const int m = n - f0;                                  // survivors of top-k
+    const int per = (m + NT - 1) / NT;
+    int first_keep = f0;
+    if (cfg.top_p > 0.f && cfg.top_p < 1.0f) {
+        const int a0 = f0 + tid * per, a1 = min(n, a0 + per);
+        double loc = 0.0;
+        for (int i = a0; i < a1; ++i) loc += (double)expf(cval[i] - smax);
+        double tot;
+        double base = block_excl_scan<NT>(loc, shd, tot);
+        int drop = 0;
+        double run = base;
+        for (int i = a0; i < a1; ++i) {
+            run += (double)expf(cval[i] - smax);
+            if (i < n - 1 && (float)(run / tot) <= cfg.one_minus_top_p) drop++;
+        }
+        double dtot;
+        (void)block_excl_scan<NT>((double)drop, shd, dtot);
+        first_keep = f0 + (int)dtot;          // cum is monotone: the dropped ones are a prefix
+    }
+    // draw: walk kept tokens from the top (position n-1 down to first_keep)
+    const int nk = n - first_keep;
+    const int perk = (nk + NT - 1) / NT;
+    const int r0 = tid * perk, r1 = min(nk, r0 + perk);    // ranks from the top
+    double loc = 0.0;
+    for (int r = r0; r < r1; ++r) loc += (double)expf(cval[n - 1 - r] - smax);
+    double tot;
+    double base = block_excl_scan<NT>(loc, shd, tot);
+    uint32_t rnd[4];
+    philox4x32_10(step, b, c, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    const double u = (double)((float)(rnd[0] >> 8) * (1.0f / 16777216.0f));
+    const double target = u * tot;
+    if (tid == 0) sh_i[1] = 0x7fffffff;
+    __syncthreads();
+    double run = base;
+    for (int r = r0; r < r1; ++r) {
+        run += (double)expf(cval[n - 1 - r] - smax);
+        if (run > target) { atomicMin(&sh_i[1], r); break; }
+    }
+    __syncthreads();
+    int r = sh_i[1];
+    if (r >= nk) r = nk - 1;                    // u*tot rounding: fall back to the last kept token
+    return cidx[n - 1 - r];
 }
 
 __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
@@ -257,6 +346,7 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
     __shared__ float cval[SAMP_CAND];
     __shared__ int cidx[SAMP_CAND];
     __shared__ float shf[SAMP_T / 64];
+    __shared__ double shd[SAMP_T / 64];
     __shared__ int shi[SAMP_T / 64];
     __shared__ int sh_i[4];
     const int tid = threadIdx.x;
@@ -303,86 +393,51 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
         if (tid == 0) decisions[out_slot] = amax;
         return;
     }
-    if (n > SAMP_CAND || n == 0) {               // loud failure: flag + argmax keeps the loop defined
-        if (tid == 0) { if (n > SAMP_CAND) atomicExch(err, 1); decisions[out_slot] = amax; }
+    if (n > SAMP_CAND || n == 0) {               // too many candidates: hand the row to the full-vocabulary kernel
+        if (tid == 0) { decisions[out_slot] = amax; if (n > SAMP_CAND) sc.overflow[b] = 1; }
         return;
     }
-    // bitonic sort of P = next_pow2(n) slots by (score asc, id asc); padding sorts last
-    int P = 1;
-    while (P < n) P <<= 1;
-    for (int i = n + tid; i < P; i += SAMP_T) { cval[i] = INFINITY; cidx[i] = 0x7fffffff; }
+    const int pick = finish_sample<SAMP_T>(cval, cidx, n, cfg, smax, (uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, seed, shd, sh_i);
+    if (tid == 0) decisions[out_slot] = pick;
+}
+
+// Full-vocabulary path (no top_k, or more than SAMP_CAND candidates): same rules on the whole row, sorted in
+// global memory by one 1024-thread block per row.  Runs only for rows the final kernel flagged.
+#define SAMP_FT 1024
+__global__ __launch_bounds__(SAMP_FT) void sample_full_kernel(
+    const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, uint64_t seed,
+    int32_t* __restrict__ decisions, SampleScratch sc, int full_cap, int single_vocab, int single_mask, int single_step,
+    int single_channel) {
+    __shared__ float shf[SAMP_FT / 64];
+    __shared__ double shd[SAMP_FT / 64];
+    __shared__ int shi[SAMP_FT / 64];
+    __shared__ int sh_i[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!sc.overflow[b]) return;
+    SampleCtx x;
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+                    single_step, single_channel)) return;
+    const MttsSamplerCfg cfg = cfgs[x.c];
+    float* val = sc.full_val + (size_t)b * full_cap;
+    int* idx = sc.full_idx + (size_t)b * full_cap;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    if (tid < SAMP_NS) { bv = sc.slice_val[b * SAMP_NS + tid]; bi = sc.slice_idx[b * SAMP_NS + tid]; }
+    block_argmax(bv, bi, shf, shi);
+    const float smax = bv;
+    // compact the finite scores (ascending id per thread chunk; order is fixed by the sort anyway)
+    if (tid == 0) sh_i[0] = 0;
     __syncthreads();
-    for (int kk = 2; kk <= P; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < P; t += SAMP_T) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    bool up = ((t & kk) == 0);
-                    float a = cval[t], bb = cval[ixj];
-                    int ai = cidx[t], bi2 = cidx[ixj];
-                    bool gt = (a > bb) || (a == bb && ai > bi2);
-                    if (gt == up) { cval[t] = bb; cval[ixj] = a; cidx[t] = bi2; cidx[ixj] = ai; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // top-k (HF TopKLogitsWarper): drop scores < k-th largest; ties with the k-th stay
-    int f0 = 0;
-    if (cfg.top_k > 0 && cfg.top_k < n) {
-        const float thr = cval[n - cfg.top_k];
-        int cnt = 0;
-        for (int i = tid; i < n; i += SAMP_T) cnt += (cval[i] < thr) ? 1 : 0;
-        float tot;
-        (void)block_excl_scan((float)cnt, shf, tot);
-        f0 = (int)tot;
-    }
-    // top-p (HF TopPLogitsWarper): ascending cumulative softmax over the survivors; drop cum <= 1-p,
-    // always keep the last (most probable) one.  Thread t owns a contiguous run of the kept range.
-    const int m = n - f0;                                  // survivors of top-k
-    const int per = (m + SAMP_T - 1) / SAMP_T;
-    int first_keep = f0;
-    if (cfg.top_p > 0.f && cfg.top_p < 1.0f) {
-        const int a0 = f0 + tid * per, a1 = min(n, a0 + per);
-        float loc = 0.f;
-        for (int i = a0; i < a1; ++i) loc += expf(cval[i] - smax);
-        float tot;
-        float base = block_excl_scan(loc, shf, tot);
-        int drop = 0;
-        float run = base;
-        for (int i = a0; i < a1; ++i) {
-            run += expf(cval[i] - smax);
-            if (i < n - 1 && run / tot <= cfg.one_minus_top_p) drop++;
-        }
-        float dtot;
-        (void)block_excl_scan((float)drop, shf, dtot);
-        first_keep = f0 + (int)dtot;          // cum is monotone: the dropped ones are a prefix
-    }
-    // draw: walk kept tokens from the top (position n-1 down to first_keep)
-    const int nk = n - first_keep;
-    const int perk = (nk + SAMP_T - 1) / SAMP_T;
-    const int r0 = tid * perk, r1 = min(nk, r0 + perk);    // ranks from the top
-    float loc = 0.f;
-    for (int r = r0; r < r1; ++r) loc += expf(cval[n - 1 - r] - smax);
-    float tot;
-    float base = block_excl_scan(loc, shf, tot);
-    uint32_t rnd[4];
-    philox4x32_10((uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-    const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
-    const float target = u * tot;
-    if (tid == 0) sh_i[1] = 0x7fffffff;
-    __syncthreads();
-    float run = base;
-    for (int r = r0; r < r1; ++r) {
-        run += expf(cval[n - 1 - r] - smax);
-        if (run > target) { atomicMin(&sh_i[1], r); break; }
+    for (int i = tid; i < x.V; i += SAMP_FT) {
+        const float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
+        if (s > -INFINITY) { const int slot = atomicAdd(&sh_i[0], 1); val[slot] = s; idx[slot] = i; }
     }
     __syncthreads();
-    if (tid == 0) {
-        int r = sh_i[1];
-        if (r >= nk) r = nk - 1;                // u*tot rounding: fall back to the last kept token
-        decisions[out_slot] = cidx[n - 1 - r];
-    }
+    const int n = sh_i[0];
+    __syncthreads();
+    int pick = bi;
+    if (n > 0) pick = finish_sample<SAMP_FT>(val, idx, n, cfg, smax, (uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, seed, shd, sh_i);
+    if (tid == 0) { decisions[b * 8 + x.c] = pick; sc.overflow[b] = 0; }
 }
 
 // One block; thread b handles sequence b.  Restates modeling_asteroid.py:139-169.
@@ -469,7 +524,7 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
 static SampleScratch g_dummy_scratch;
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps, int bm_words,
                    const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions, int32_t* err,
-                   int B, const SampleScratch& sc, int ch0_sampled, hipStream_t st) {
+                   int B, const SampleScratch& sc, int ch0_sampled, int full_cap, hipStream_t st) {
     const int big0 = V0 > SAMP_CAND ? 1 : 0;
     if (big0) {
         hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
@@ -481,10 +536,13 @@ void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, in
     hipLaunchKernelGGL(sample_final_kernel, dim3(8, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0,
                        (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seed, decisions, err, sc,
                        big0, 0, 0, 0, 0);
+    if (big0 && ch0_sampled)
+        hipLaunchKernelGGL(sample_full_kernel, dim3(B), dim3(SAMP_FT), 0, st, (const uint16_t*)logits0, V0, bitmaps,
+                           bm_words, cfgs, ls, seed, decisions, sc, full_cap, 0, 0, 0, 0);
 }
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
-                          int32_t* decisions, int32_t* err, const SampleScratch& sc, hipStream_t st) {
+                          int32_t* decisions, int32_t* err, const SampleScratch& sc, int full_cap, hipStream_t st) {
     if (vocab > SAMP_CAND) {
         hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
                            bitmap, bm_words, cfgs8, (const LoopState*)nullptr, sc, vocab, mask_id, step, channel);
@@ -494,6 +552,10 @@ void launch_sample_single(const void* logits, int rows, int vocab, const uint32_
     hipLaunchKernelGGL(sample_final_kernel, dim3(1, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits,
                        (const uint16_t*)nullptr, vocab, vocab, vocab, bitmap, bm_words, cfgs8, (const LoopState*)nullptr,
                        seed, decisions, err, sc, 1, vocab, mask_id, step, channel);
+    if (vocab > SAMP_CAND)
+        hipLaunchKernelGGL(sample_full_kernel, dim3(rows), dim3(SAMP_FT), 0, st, (const uint16_t*)logits, vocab, bitmap,
+                           bm_words, cfgs8, (const LoopState*)nullptr, seed, decisions, sc, full_cap, vocab, mask_id, step,
+                           channel);
 }
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,

@@ -98,6 +98,28 @@ def test_sampler_kernel_vs_oracle():
             assert all(np.isfinite(sc[b, got[b]]) for b in range(rows))      # always inside the kept set
             mism += int((want != got).sum())
         assert mism <= 1, mism      # fp32-vs-fp64 cumsum can move a boundary draw (p ~ 1e-6 each)
+        # no top_k (nucleus only), plain multinomial, and a top_k beyond the candidate buffer: on the big vocabulary
+        # these take the full-vocabulary kernel (global-memory sort), on 1025 tokens the in-block path
+        for lc in (dict(top_p=0.9), dict(temperature=1.3), dict(top_k=6000, top_p=0.97, repetition_penalty=1.2)):
+            sc = ao.apply_processors(hist, logits, lc)
+            mism = 0
+            for step in range(12):
+                want = ao.sample_from_scores(sc, 99, step, 0)
+                got = _sample_gpu(logits, hist, lc, True, -1, 99, step, 0)
+                mism += int((want != got).sum())
+                # A nucleus over ~150 k tokens has members of 1e-6 probability: which of them sit on the top-p
+                # boundary is decided by fp32 noise in the reference's own cumsum, and that moves `total` by ~1e-5.
+                # So require the engine's pick to be the token whose CDF interval contains u within 1e-4 of mass.
+                for b in range(rows):
+                    kept = np.nonzero(np.isfinite(sc[b]))[0]
+                    kept = kept[np.lexsort((kept, sc[b][kept]))[::-1]]
+                    e = np.exp((sc[b][kept] - sc[b][kept].max()).astype(np.float32)).astype(np.float64)
+                    cum = np.cumsum(e) / e.sum()
+                    u = float(ao.philox_uniform(99, step, b, 0))
+                    j = int(np.nonzero(kept == got[b])[0][0])        # raises if the pick is outside the kept set
+                    lo = cum[j - 1] if j else 0.0
+                    assert lo - 1e-4 <= u <= cum[j] + 1e-4, (lc, V, b, step, lo, u, cum[j])
+            assert mism <= (2 if V < 5000 else 12), (lc, V, mism)
 
 
 def _load_case(golden_dir, name):
