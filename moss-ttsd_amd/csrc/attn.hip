@@ -22,7 +22,7 @@ template <int G>
 __global__ __launch_bounds__(256) void attn_scores_kernel(
     const uint16_t* __restrict__ qbuf, const u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
     const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
-    int nq, int nkv, float scale, const int32_t* __restrict__ done) {
+    int total_pages, int nq, int nkv, float scale, const int32_t* __restrict__ done) {
     __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
     if (done && *done) return;
     const int r = blockIdx.z, kvh = blockIdx.y;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     u32x4_t kv[16];
     if (pg < npages) {
         const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* kp = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+        const u32x4_t* kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
         for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
     }
@@ -91,7 +91,7 @@ template <int G>
 __global__ __launch_bounds__(256) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, const u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
-    int max_pages, int nchunks_max, int nq, int nkv, const int32_t* __restrict__ done) {
+    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, const int32_t* __restrict__ done) {
     __shared__ float red[4][G][MTTS_HD];
     __shared__ uint16_t pbuf[4][G][MTTS_PAGE];
     if (done && *done) return;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     int pg = chunk * ATT_PB + wave * (ATT_PB / 4);
     if (pg < npages) {
         const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+        const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
         for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
     }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
         if (pg >= npages) break;
         if (pp > 0) {
             const int page = page_table[(size_t)m.seq * max_pages + pg];
-            const u32x4_t* vp = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+            const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
             for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
         }
@@ -205,17 +205,17 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 template <int G>
 static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
-                          int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale,
+                          int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                           const int32_t* done, int phase, hipStream_t st) {
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
         hipLaunchKernelGGL((attn_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
-                           page_table, meta, (uint16_t*)scores, stats, max_pages, nq, nkv, scale, done);
+                           page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, done);
     }
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
         hipLaunchKernelGGL((attn_pv_kernel<G>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
-                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, nchunks_max, nq, nkv, done);
+                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, done);
     }
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
@@ -224,12 +224,12 @@ static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcac
 
 int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
-                int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
+                int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
                 int phase, hipStream_t st) {
     int G = nq / nkv;
 #define MTTS_ATT(GG)                                                                                              \
     launch_attn_g<GG>(qbuf, kcache, vcache, page_table, meta, scores, stats, opart, out_packed, R, pages_bound,   \
-                      max_pages, nchunks_max, nq, nkv, scale, done, phase, st)
+                      max_pages, total_pages, nchunks_max, nq, nkv, scale, done, phase, st)
     if (G == 1) MTTS_ATT(1);
     else if (G == 2) MTTS_ATT(2);
     else if (G == 4) MTTS_ATT(4);

@@ -35,13 +35,13 @@ void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, cons
                        void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st);
 void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
-                     const int32_t* page_table, int max_pages, int R, int nq, int nkv, float eps, const int32_t* done,
-                     hipStream_t st);
+                     const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
+                     const int32_t* done, hipStream_t st);
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st);
 int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
-                int pages_bound, int max_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
-                int phase, hipStream_t st);
+                int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
+                const int32_t* done, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, pad; };
 struct LoopState { int32_t step, done, base_length, max_length, tf_len, B, error, pad; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
@@ -417,12 +417,12 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
         launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
-                        kc, vc, e->d_page_table, e->max_pages, R, nq, nkv, eps, done, st);
+                        kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
         for (int phase = 1; phase <= 3; ++phase) {
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
-                            pages_bound, e->max_pages, e->nchunks_max, nq, nkv, scale, done, phase, st))
+                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale, done, phase, st))
                 return fail(MTTS_EINVAL, "attention group size not built");
             if (phase < 3) prof_end(e, st, ev);
         }

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
 // QKV epilogue: split-K reduce -> bf16; per-head q/k RMSNorm (modeling_qwen3.py
 // :251-252); RoPE in bf16 with three roundings (:148-170); q to qbuf, k/v into
 // the paged cache (replaces DynamicCache.update's torch.cat, :258-259).
-//   K page layout: [page][kvh][d/8][token 0..63][8]   (token-major inner: the
+//   cache layout per layer: [kvh][page][16 KiB]  (a sequence's consecutive pages of one head are contiguous)
+//   K page layout: [d/8][token 0..63][8]   (token-major inner: the
 //   score kernel reads one token per lane with no cross-lane reduction)
 //   V page layout: [page][kvh][token pair 0..31][d 0..127][2]  (P.V as v_dot2c against packed p pairs)
 // grid = (R, nq + 2*nkv), block 64 (lane l owns d = l and d = l+64).
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
     const uint16_t* __restrict__ rope_cos, const uint16_t* __restrict__ rope_sin,
     uint16_t* __restrict__ qbuf /*[R][nq][128]*/, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
-    const int32_t* __restrict__ page_table, int max_pages, int nq, int nkv, float eps,
+    const int32_t* __restrict__ page_table, int max_pages, int total_pages, int nq, int nkv, float eps,
     const int32_t* __restrict__ done) {
     if (done && *done) return;
     const int r = blockIdx.x, h = blockIdx.y, l = threadIdx.x;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     if (h >= nq + nkv) {   // V head: no norm, no rope
         const int kvh = h - nq - nkv;
         // V page layout [token pair][d][2]: element (tok, d) at ((tok>>1)*128 + d)*2 + (tok&1)
-        uint16_t* dst = vcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD) + (size_t)(tok >> 1) * (MTTS_HD * 2) + (tok & 1);
+        uint16_t* dst = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD) + (size_t)(tok >> 1) * (MTTS_HD * 2) + (tok & 1);
         dst[2 * l] = f2bf(a);
         dst[2 * (l + 64)] = f2bf(b);
         return;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
         dst[l + 64] = f2bf(o2);
     } else {
         const int kvh = h - nq;
-        uint16_t* base = kcache + ((size_t)page * nkv + kvh) * (MTTS_PAGE * MTTS_HD);
+        uint16_t* base = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD);
         // element (tok, d) at ((d/8)*64 + tok)*8 + d%8
         base[(((l >> 3) * 64) + tok) * 8 + (l & 7)] = f2bf(o1);
         base[((((l + 64) >> 3) * 64) + tok) * 8 + (l & 7)] = f2bf(o2);
@@ -208,11 +209,11 @@ void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, cons
 }
 void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
-                     const int32_t* page_table, int max_pages, int R, int nq, int nkv, float eps, const int32_t* done,
-                     hipStream_t st) {
+                     const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
+                     const int32_t* done, hipStream_t st) {
     hipLaunchKernelGGL(qkv_post_kernel, dim3(R, nq + 2 * nkv), dim3(64), 0, st, partial, ksplit, Npad, meta,
                        (const uint16_t*)qnw, (const uint16_t*)knw, (const uint16_t*)cosb, (const uint16_t*)sinb,
-                       (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, nq, nkv, eps, done);
+                       (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, total_pages, nq, nkv, eps, done);
 }
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w,
