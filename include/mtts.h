@@ -129,7 +129,8 @@ int32_t mtts_profile_enable(MttsEngine* e, int32_t on);
 int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_t* launches, int64_t* bytes);
 
 /* measurement hooks (bench / profiling only, never on the product path) */
-int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len);
+int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len);   /* also fills the KV pages with pseudo-random bf16 */
+int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters, float* avg_ms, int64_t* bytes_per_launch);
 int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,
                           int32_t iters, float* avg_us);
 

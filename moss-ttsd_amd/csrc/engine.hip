@@ -38,6 +38,7 @@ void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* 
                      const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
                      const int32_t* done, hipStream_t st);
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st);
+void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st);
 int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
@@ -817,6 +818,51 @@ extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
     for (int b = 0; b < e->B; ++b) { ss[b].kv_len = kv_len; e->n_real[b] = kv_len - e->steps_issued; }
     e->max_real = kv_len - e->steps_issued;
     HIPCHK(hipMemcpy(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice));
+    launch_fill_random_bf16(e->kcache, e->layer_stride * e->L, 0x1234u, nullptr);
+    launch_fill_random_bf16(e->vcache, e->layer_stride * e->L, 0x9876u, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    return MTTS_OK;
+}
+
+// Measurement hook: `iters` back-to-back launches of one attention pass (phase 1 = scores, 2 = PV) at the
+// engine's CURRENT decode state, cycling over the layers' caches; average duration from two HIP events on the
+// launch stream.  (Events around a single launch also time the launch gap, which rocprof's kernel duration
+// does not; a train of launches does not have that bias.)
+extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters, float* avg_ms, int64_t* bytes_per_launch) {
+    if (!e || !e->began || (phase != 1 && phase != 2) || iters < 1 || !avg_ms) return fail(MTTS_EINVAL, "attn_bench: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const float scale = 1.0f / sqrtf((float)MTTS_HD);
+    const int R = round_up(e->B, 32);
+    const int len_bound = e->max_real + e->steps_issued + 1;
+    const int pages_bound = (len_bound + MTTS_PAGE - 1) / MTTS_PAGE;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](int n) {
+        for (int i = 0; i < n; ++i) {
+            const int layer = i % e->L;
+            uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * layer;
+            uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * layer;
+            launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
+                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, nullptr, phase, nullptr);
+        }
+    };
+    run(e->L);                               // warm-up
+    hipEventRecord(e0, nullptr);
+    run(iters);
+    hipEventRecord(e1, nullptr);
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *avg_ms = ms / iters;
+    if (bytes_per_launch) {
+        std::vector<RowMeta> m(MTTS_RCAP);
+        HIPCHK(hipMemcpy(m.data(), e->d_meta, m.size() * sizeof(RowMeta), hipMemcpyDeviceToHost));
+        int64_t tok = 0;
+        for (int b = 0; b < R; ++b) if (m[b].seq >= 0) tok += m[b].pos + 1;
+        *bytes_per_launch = tok * e->nkv * MTTS_HD * 2;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
     return MTTS_OK;
 }
 

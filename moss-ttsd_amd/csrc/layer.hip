@@ -219,3 +219,17 @@ void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n,
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w,
                        (uint16_t*)y, n, eps);
 }
+
+// Measurement aid: pseudo-random bf16 values in (-1, 1) (profiling runs jump to a long context without replaying it;
+// timing HBM-bound kernels on zeros would flatter them).
+__global__ void fill_random_bf16_kernel(uint16_t* __restrict__ p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        const float v = ((float)(h & 0xffffff) / 8388608.0f) - 1.0f;
+        p[i] = f2bf(v);
+    }
+}
+void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, st, (uint16_t*)p, n, seed);
+}

@@ -163,6 +163,13 @@ class Engine:
     def debug_set_kv_len(self, n):
         capi.check(self.lib.mtts_debug_set_kv_len(self._h, int(n)))
 
+    def attn_bench(self, phase, iters=112):
+        """-> (avg ms per launch, algorithmic bytes per launch) of attention pass `phase` (1 scores, 2 PV) at the
+        current decode state, measured over a train of back-to-back launches."""
+        ms, by = C.c_float(0), C.c_int64(0)
+        capi.check(self.lib.mtts_k_attn_bench(self._h, int(phase), int(iters), C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
     def profile(self, on=True):
         capi.check(self.lib.mtts_profile_enable(self._h, 1 if on else 0))
 
