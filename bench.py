@@ -104,7 +104,7 @@ def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
     return step_time, per_layer, min(t_heads)
 
 
-def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=8):
+def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=32):
     """End-to-end figure: prefill + every decode step run so far + codec decode of ALL the
     frames this run generated (full-depth XY_Tokenizer decoder, 30 s windows / 20 s stride as the reference)."""
     import torch

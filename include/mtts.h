@@ -54,7 +54,7 @@ typedef struct MttsConfig {
     int32_t eos_token_id;
     int32_t max_position;          /* rows in the RoPE table */
     float rms_norm_eps;
-    int32_t max_batch;             /* sequences resident at once */
+    int32_t max_batch;             /* sequences resident at once (1..128: up to 4 MFMA row tiles share each weight stream) */
     int32_t max_seq_len;           /* real tokens per sequence the KV pool is sized for */
 } MttsConfig;
 

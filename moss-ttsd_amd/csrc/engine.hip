@@ -12,7 +12,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -143,7 +142,6 @@ struct MttsEngine {
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_N];
-    std::vector<hipEvent_t> ev_pool;
     int64_t prof_bytes[PROF_N] = {0, 0, 0, 0};
 };
 
