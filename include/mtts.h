@@ -119,6 +119,16 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
 int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_steps, int32_t* n_steps);
 /* last forward's logits: bf16 bits, channel 0 [B,vocab_size], channels 1..7 [7,B,speech_vocab_size] */
 int32_t mtts_read_logits(MttsEngine* e, uint16_t* host_logits0, uint16_t* host_logits17, void* stream);
+/* ---- continuous batching: slots are refilled while other dialogues are mid-flight ---------
+ * mtts_sched_open: B empty slots, gen_cap rows of token storage each.  mtts_slot_submit: prefill ONE delay-shifted
+ * prompt (host int64 [T][8], no padding) into an empty slot; its Philox stream is (seed; step, 0, channel).
+ * mtts_step advances every occupied slot; a finished dialogue leaves the batch at once.  mtts_slot_states:
+ * int32 [B][4] = (active, unfinished, rows generated, tokens cached).  mtts_slot_read: its rows int64 [steps][8]. */
+int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSamplerCfg* sampler, void* stream);
+int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* host_ids, int32_t T, int32_t max_length, uint64_t seed,
+                         void* stream);
+int32_t mtts_slot_states(MttsEngine* e, int32_t* host_state, void* stream);
+int32_t mtts_slot_read(MttsEngine* e, int32_t slot, int64_t* host_rows, int32_t capacity_steps, int32_t* n_steps);
 int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream);
 /* Frames first..first+n-1 as codec codes int64 [8][B][n] on the device (delay pattern undone, generation_utils.py:416-425);
  * `stream` must be ordered after the steps that produced frame first+n+6. */

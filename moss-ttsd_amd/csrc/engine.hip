@@ -42,14 +42,15 @@ int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const 
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                 const int32_t* done, int phase, hipStream_t st);
-struct SeqState { int32_t nas, unfinished, kv_len, pad; };
-struct LoopState { int32_t step, done, base_length, max_length, tf_len, B, error, pad; };
+struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
+struct LoopState { int32_t step, done, continuous, B, error, gen_cap, pad0, pad1; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
 #define SAMP_CAND 4096
 #define SAMP_NS 32
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps,
-                   int bm_words, const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions,
-                   int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, int full_cap, hipStream_t st);
+                   int bm_words, const MttsSamplerCfg* cfgs, const LoopState* ls, const SeqState* seqs, uint64_t seed,
+                   int32_t* decisions, int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, int full_cap,
+                   hipStream_t st);
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
                           int32_t* decisions, int32_t* err, const SampleScratch& sc, int full_cap, hipStream_t st);
@@ -58,11 +59,10 @@ static int full_cap_for(int vocab) { int p = 1; while (p < vocab) p <<= 1; retur
 static void free_scratch(SampleScratch& sc);
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
-                   LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
-                   hipStream_t st);
+                   LoopState* ls, int eos, int spad, int sp_lo, int sp_hi, hipStream_t st);
 
 void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
-                         hipStream_t st);
+                         int cap, hipStream_t st);
 #define ATT_PB 8
 
 // ---- errors -------------------------------------------------------------------
@@ -108,7 +108,7 @@ struct MttsEngine {
     // workspaces
     float* partial = nullptr;
     void *x = nullptr, *xn = nullptr, *attn_p = nullptr, *act_p = nullptr, *qbuf = nullptr, *hlast = nullptr, *xh = nullptr;
-    void *logits0 = nullptr, *logits17 = nullptr;
+    void *logits0 = nullptr, *logits17 = nullptr, *join_logits0 = nullptr, *join_logits17 = nullptr;
     void* scores = nullptr;
     float *stats = nullptr, *opart = nullptr;
     // kv
@@ -135,6 +135,8 @@ struct MttsEngine {
     int gen_cap = 0;
     // current run
     int B = 0, T = 0, base_length = 0, max_length = 0, max_steps = 0, steps_issued = 0;
+    bool continuous = false;
+    std::vector<int> join_step;         // engine step at which each slot's dialogue joined
     std::vector<int> n_real;
     int max_real = 0;
     uint64_t seed = 0;
@@ -244,6 +246,8 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_RCAP * e->nq * MTTS_HD));
     TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
     TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
+    TRY(dalloc((uint16_t**)&e->join_logits0, (size_t)MTTS_MAXR * e->V0));
+    TRY(dalloc((uint16_t**)&e->join_logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
     // KV pool
     e->max_pages = (c->max_seq_len + MTTS_PAGE - 1) / MTTS_PAGE + 1;
     e->total_pages = e->max_pages * c->max_batch;
@@ -283,7 +287,7 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
     }
     for (int c = 0; c < 8; ++c) hipFree(e->emb[c]);
     void* ptrs[] = {e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
-                    e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->scores, e->stats,
+                    e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->join_logits0, e->join_logits17, e->scores, e->stats,
                     e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
                     e->d_cur, e->d_gen, e->d_declog, e->d_forced, e->d_tf, e->d_bitmaps, e->d_scfg, e->d_pf_tokens,
                     e->d_pf_meta};
@@ -453,6 +457,18 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     return MTTS_OK;
 }
 
+// generated-token storage [slot][gen_cap][8] (+ decision log and forced rows of the same shape)
+static int ensure_gen_storage(MttsEngine* e, int steps) {
+    if (steps <= e->gen_cap) return 0;
+    if (e->d_gen) { hipFree(e->d_gen); hipFree(e->d_declog); hipFree(e->d_forced); }
+    e->gen_cap = steps;
+    const size_t n = (size_t)e->cfg.max_batch * steps * 8;
+    TRY(dalloc(&e->d_gen, n));
+    TRY(dalloc(&e->d_declog, n));
+    TRY(dalloc(&e->d_forced, n, false));
+    return 0;
+}
+
 // ---- begin: parse prompt, allocate pages, prefill --------------------------------------
 int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32_t B, int32_t T, int32_t max_length,
                    const MttsSamplerCfg* sampler, uint64_t seed, void* stream) {
@@ -491,13 +507,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     if (e->max_real + max_steps > e->rope_rows)
         return fail(MTTS_EINVAL, "rope table has %d rows, need %d", e->rope_rows, e->max_real + max_steps);
     // generation buffers
-    if (max_steps > e->gen_cap) {
-        if (e->d_gen) { hipFree(e->d_gen); hipFree(e->d_declog); hipFree(e->d_forced); }
-        e->gen_cap = max_steps;
-        TRY(dalloc(&e->d_gen, (size_t)max_steps * MTTS_RCAP * 8));
-        TRY(dalloc(&e->d_declog, (size_t)max_steps * MTTS_RCAP * 8));
-        TRY(dalloc(&e->d_forced, (size_t)max_steps * MTTS_RCAP * 8, false));
-    }
+    TRY(ensure_gen_storage(e, max_steps));
     // flattened prefill rows
     size_t Mtot = 0;
     for (int b = 0; b < B; ++b) Mtot += e->n_real[b];
@@ -544,10 +554,12 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
                     tf[((size_t)b * 7 + s) * 8 + c] = (int32_t)tk;
                 }
         HIPCHK(hipMemcpyAsync(e->d_tf, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
-        std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0});
-        for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0};
+        std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
+        for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0, base, max_length, b, 1, seed};
         HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
-        LoopState ls{0, 0, base, max_length, T, B, 0, 0};
+        LoopState ls{0, 0, 0, B, 0, e->gen_cap, 0, 0};
+        e->continuous = false;
+        e->join_step.assign(MTTS_RCAP, 0);
         HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
         *e->h_ls = ls;
         std::vector<RowMeta> dm(MTTS_RCAP, RowMeta{-1, 0, 0, 0});
@@ -576,10 +588,11 @@ static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
         hipEvent_t ev = nullptr;
         prof_begin(e, PROF_STEP, st, &ev);
         launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
-                      e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled, full_cap_for(e->V0), st);
+                      e->d_seqs, e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled,
+                      full_cap_for(e->V0), st);
         launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
-                      e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, nullptr, e->cfg.eos_token_id,
-                      e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, e->max_steps, st);
+                      e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, e->cfg.eos_token_id,
+                      e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, st);
         const int len_bound = e->max_real + e->steps_issued + 1;
         const int pages_bound = (len_bound + MTTS_PAGE - 1) / MTTS_PAGE;
         // rough KV token count for the profile's byte figure: every row at its current length
@@ -612,11 +625,12 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
 static int read_rows(MttsEngine* e, const int32_t* d_src, int64_t* host, int capacity_steps, int* n_steps) {
     int steps = e->h_ls->step;
     if (steps > capacity_steps) return fail(MTTS_EINVAL, "output buffer holds %d steps, need %d", capacity_steps, steps);
-    std::vector<int32_t> tmp((size_t)steps * MTTS_RCAP * 8);
-    if (steps) HIPCHK(hipMemcpy(tmp.data(), d_src, tmp.size() * 4, hipMemcpyDeviceToHost));
-    for (int s = 0; s < steps; ++s)
-        for (int b = 0; b < e->B; ++b)
-            for (int c = 0; c < 8; ++c) host[((size_t)s * e->B + b) * 8 + c] = tmp[((size_t)s * MTTS_RCAP + b) * 8 + c];
+    std::vector<int32_t> tmp((size_t)std::max(steps, 1) * 8);
+    for (int b = 0; b < e->B; ++b) {
+        if (steps) HIPCHK(hipMemcpy(tmp.data(), d_src + (size_t)b * e->gen_cap * 8, (size_t)steps * 8 * 4, hipMemcpyDeviceToHost));
+        for (int s = 0; s < steps; ++s)
+            for (int c = 0; c < 8; ++c) host[((size_t)s * e->B + b) * 8 + c] = tmp[(size_t)s * 8 + c];
+    }
     if (n_steps) *n_steps = steps;
     return MTTS_OK;
 }
@@ -652,13 +666,13 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
     const int base = e->base_length;
     if (forced) {
         if (!decisions) return fail(MTTS_EINVAL, "forced replay needs host_decisions");
-        std::vector<int32_t> f((size_t)e->max_steps * MTTS_RCAP * 8, -1);
+        std::vector<int32_t> f((size_t)e->cfg.max_batch * e->gen_cap * 8, -1);
         for (int s = 0; s < e->max_steps && base + s < forced_len; ++s)
             for (int b = 0; b < B; ++b)
                 for (int c = 0; c < 8; ++c) {
                     int64_t tk = forced[((size_t)b * forced_len + base + s) * 8 + c];
                     if (tk < 0 || tk >= (c == 0 ? e->V0 : e->Vs)) return fail(MTTS_EINVAL, "forced token %lld out of range on channel %d", (long long)tk, c);
-                    f[((size_t)s * MTTS_RCAP + b) * 8 + c] = (int32_t)tk;
+                    f[((size_t)b * e->gen_cap + s) * 8 + c] = (int32_t)tk;
                 }
         HIPCHK(hipMemcpy(e->d_forced, f.data(), f.size() * 4, hipMemcpyHostToDevice));
         e->has_forced = true;
@@ -702,6 +716,137 @@ int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfi
     return MTTS_OK;
 }
 
+// ---- continuous batching: per-slot dialogues ---------------------------------------------------------
+// mtts_sched_open(e, B, sampler): B slots, all empty.  mtts_slot_submit(): prefill ONE dialogue into an empty slot
+// while the others keep their state.  mtts_step() then advances every occupied slot by one frame; a dialogue that
+// finishes leaves the batch at once (no finished-row padding) and its slot can be refilled.
+int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSamplerCfg* sampler, void* stream) {
+    if (!e || !sampler) return fail(MTTS_EINVAL, "null argument");
+    TRY(mtts_weights_ready(e));
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = S(stream);
+    if (B < 1 || B > e->cfg.max_batch) return fail(MTTS_EINVAL, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    if (gen_cap < 8) return fail(MTTS_EINVAL, "gen_cap too small");
+    TRY(ensure_gen_storage(e, gen_cap));
+    e->B = B; e->steps_issued = 0; e->has_forced = false; e->continuous = true;
+    e->max_steps = 1 << 30;
+    e->n_real.assign(B, 0);
+    e->join_step.assign(MTTS_RCAP, 0);
+    e->max_real = 0;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < e->max_pages; ++p) e->h_page_table[(size_t)b * e->max_pages + p] = b * e->max_pages + p;
+    HIPCHK(hipMemcpyAsync(e->d_page_table, e->h_page_table.data(), e->h_page_table.size() * 4, hipMemcpyHostToDevice, st));
+    std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
+    HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
+    LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, 0};
+    HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
+    *e->h_ls = ls;
+    std::vector<RowMeta> dm(MTTS_RCAP, RowMeta{-1, 0, 0, 0});
+    HIPCHK(hipMemcpyAsync(e->d_meta, dm.data(), dm.size() * sizeof(RowMeta), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_scfg, sampler, 8 * sizeof(MttsSamplerCfg), hipMemcpyHostToDevice, st));
+    e->ch0_sampled = sampler[0].do_sample ? 1 : 0;
+    HIPCHK(hipMemsetAsync(e->sscr.hist, 0, (size_t)e->cfg.max_batch * 2048 * 4, st));
+    HIPCHK(hipMemsetAsync(e->sscr.cand_n, 0, (size_t)e->cfg.max_batch * 4, st));
+    HIPCHK(hipMemsetAsync(e->sscr.overflow, 0, (size_t)e->cfg.max_batch * 4, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->began = true;
+    return MTTS_OK;
+}
+
+// host_ids int64 [T][8] (one delay-shifted prompt, no padding), max_length in its own padded-slot units (T + max_new).
+int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_t T, int32_t max_length, uint64_t seed,
+                         void* stream) {
+    if (!e || !e->began || !e->continuous || !ids) return fail(MTTS_ESTATE, "mtts_sched_open has not run");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = S(stream);
+    if (slot < 0 || slot >= e->B) return fail(MTTS_EINVAL, "slot %d out of range", slot);
+    if (T < 8) return fail(MTTS_EINVAL, "T must be >= 8");
+    const int base = T - 7, n = base;
+    if (max_length <= base) return fail(MTTS_EINVAL, "max_length leaves no room to generate");
+    const int max_new = max_length - base;
+    if (max_new > e->gen_cap) return fail(MTTS_EINVAL, "dialogue may run %d steps, slot storage holds %d", max_new, e->gen_cap);
+    if ((n + max_new + MTTS_PAGE - 1) / MTTS_PAGE > e->max_pages) return fail(MTTS_ENOMEM, "dialogue needs more KV pages than a slot has");
+    if (n + max_new > e->rope_rows) return fail(MTTS_EINVAL, "rope table too short");
+    HIPCHK(hipStreamSynchronize(st));
+    {   // the slot must be empty
+        SeqState cur;
+        HIPCHK(hipMemcpy(&cur, e->d_seqs + slot, sizeof(cur), hipMemcpyDeviceToHost));
+        if (cur.active) return fail(MTTS_ESTATE, "slot %d is occupied", slot);
+    }
+    const size_t Mpad = ((size_t)n + MTTS_RCAP - 1) / MTTS_RCAP * MTTS_RCAP;
+    std::vector<int32_t> toks(Mpad * 8, 0);
+    std::vector<RowMeta> metas(Mpad, RowMeta{-1, 0, 0, 0});
+    std::vector<uint32_t> bm((size_t)8 * e->bm_words, 0u);
+    std::vector<int32_t> tf(7 * 8, 0);
+    for (int i = 0; i < T; ++i)
+        for (int c = 0; c < 8; ++c) {
+            int64_t t = ids[(size_t)i * 8 + c];
+            if (t < 0 || t >= (c == 0 ? e->V0 : e->Vs)) return fail(MTTS_EINVAL, "token %lld out of range on channel %d", (long long)t, c);
+            if (i < n) { toks[(size_t)i * 8 + c] = (int32_t)t; bm[(size_t)c * e->bm_words + (t >> 5)] |= 1u << (t & 31); }
+            else tf[(i - n) * 8 + c] = (int32_t)t;
+        }
+    for (int i = 0; i < n; ++i) metas[i] = RowMeta{slot, i, i == n - 1 ? 1 : 0, 0};
+    if (Mpad > e->pf_cap_rows) {
+        if (e->d_pf_tokens) { hipFree(e->d_pf_tokens); hipFree(e->d_pf_meta); }
+        TRY(dalloc(&e->d_pf_tokens, Mpad * 8, false));
+        TRY(dalloc(&e->d_pf_meta, Mpad, false));
+        e->pf_cap_rows = Mpad;
+    }
+    HIPCHK(hipMemcpy(e->d_pf_tokens, toks.data(), Mpad * 8 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_pf_meta, metas.data(), Mpad * sizeof(RowMeta), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_bitmaps + (size_t)slot * 8 * e->bm_words, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_tf + (size_t)slot * 7 * 8, tf.data(), tf.size() * 4, hipMemcpyHostToDevice));
+    const int pages_bound = (n + MTTS_PAGE - 1) / MTTS_PAGE;
+    for (size_t off = 0; off < Mpad; off += MTTS_RCAP)
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_RCAP, pages_bound, 0, nullptr, st, 0));
+    // logits of the dialogue's last prompt token only: heads on a one-row activation tile, copied into its slot
+    // (the other slots' logits belong to dialogues that are mid-flight)
+    HIPCHK(hipMemsetAsync(e->xh, 0, (size_t)MTTS_MAXR * e->H * 2, st));
+    launch_pack_rows((const uint16_t*)e->hlast + (size_t)slot * e->H, e->xh, 1, e->H, 1, st);
+    launch_gemm(EPI_BF16, 1, e->p_h0, e->head0, e->xh, e->H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->join_logits0, st);
+    launch_gemm(EPI_BF16, 1, e->p_h17, e->heads17, e->xh, e->H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->join_logits17, st);
+    HIPCHK(hipMemcpyAsync((uint16_t*)e->logits0 + (size_t)slot * e->V0, e->join_logits0, (size_t)e->V0 * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync((uint16_t*)e->logits17 + (size_t)slot * 7 * e->Vs_pad, e->join_logits17, (size_t)7 * e->Vs_pad * 2, hipMemcpyDeviceToDevice, st));
+    SeqState ns{-1, 1, n, 0, base, max_length, 0, 1, seed};
+    HIPCHK(hipMemcpyAsync(e->d_seqs + slot, &ns, sizeof(ns), hipMemcpyHostToDevice, st));
+    int32_t zero = 0;
+    HIPCHK(hipMemcpyAsync(&e->d_ls->done, &zero, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->n_real[slot] = n - e->steps_issued;          // so that n_real + steps_issued is this dialogue's current length
+    e->join_step[slot] = e->steps_issued;
+    e->max_real = *std::max_element(e->n_real.begin(), e->n_real.end());
+    return MTTS_OK;
+}
+
+// host_state int32 [B][4] = (active, unfinished, steps generated, tokens in cache)
+int32_t mtts_slot_states(MttsEngine* e, int32_t* host_state, void* stream) {
+    if (!e || !e->began || !host_state) return fail(MTTS_ESTATE, "engine not started");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<SeqState> ss(MTTS_RCAP);
+    HIPCHK(hipMemcpyAsync(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    for (int b = 0; b < e->B; ++b) {
+        host_state[b * 4 + 0] = ss[b].active; host_state[b * 4 + 1] = ss[b].unfinished;
+        host_state[b * 4 + 2] = ss[b].step; host_state[b * 4 + 3] = ss[b].kv_len;
+    }
+    return MTTS_OK;
+}
+
+// generated rows of one slot: host_rows int64 [steps][8]
+int32_t mtts_slot_read(MttsEngine* e, int32_t slot, int64_t* host_rows, int32_t capacity_steps, int32_t* n_steps) {
+    if (!e || !e->began || !host_rows || slot < 0 || slot >= e->B) return fail(MTTS_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    SeqState cur;
+    HIPCHK(hipMemcpy(&cur, e->d_seqs + slot, sizeof(cur), hipMemcpyDeviceToHost));
+    if (cur.step > capacity_steps) return fail(MTTS_EINVAL, "buffer holds %d steps, need %d", capacity_steps, cur.step);
+    std::vector<int32_t> tmp((size_t)std::max(cur.step, 1) * 8);
+    if (cur.step) HIPCHK(hipMemcpy(tmp.data(), e->d_gen + (size_t)slot * e->gen_cap * 8, (size_t)cur.step * 8 * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cur.step * 8; ++i) host_rows[i] = tmp[i];
+    if (n_steps) *n_steps = cur.step;
+    return MTTS_OK;
+}
+
 // Frames first..first+n-1 of every sequence as codec codes int64 [8][B][n] on the device (delay pattern undone,
 // channel-0 offset removed): lets the codec decode windows while the decode loop is still running.  The caller
 // orders `stream` after the steps that produced frame first+n+6 (event / same stream).
@@ -709,7 +854,7 @@ int32_t mtts_export_codes(MttsEngine* e, int32_t first, int32_t n, int64_t* dev_
     if (!e || !e->began || !dev_codes) return fail(MTTS_ESTATE, "nothing generated");
     if (first < 0 || n < 1 || first + n + 7 > e->steps_issued) return fail(MTTS_EINVAL, "frames %d..%d need %d issued steps, have %d", first, first + n - 1, first + n + 7, e->steps_issued);
     HIPCHK(hipSetDevice(e->device));
-    launch_export_codes(e->d_gen, dev_codes, e->B, first, n, e->cfg.speech_range_lo, e->cfg.speech_vocab_size - 2, S(stream));
+    launch_export_codes(e->d_gen, dev_codes, e->B, first, n, e->cfg.speech_range_lo, e->cfg.speech_vocab_size - 2, e->gen_cap, S(stream));
     HIPCHK(hipGetLastError());
     return MTTS_OK;
 }

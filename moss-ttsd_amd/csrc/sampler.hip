@@ -16,22 +16,28 @@
 #include "../../include/mtts.h"
 
 
-struct SeqState {           // one per sequence slot, device resident
+struct SeqState {           // one per sequence slot, device resident.  Every dialogue carries its own clock so
+                            // that slots can be refilled while others are mid-flight (continuous batching).
     int32_t nas;            // needs_additional_steps
     int32_t unfinished;
     int32_t kv_len;         // real tokens already in the KV cache
-    int32_t pad;
+    int32_t step;           // decode steps this dialogue has run (= rows it generated)
+    int32_t base_length;    // T-7 (padded slots) of its prompt
+    int32_t max_length;     // HF max_length in padded slots
+    int32_t row_id;         // Philox counter word 1 (batch row index in mtts_generate, 0 for scheduled dialogues)
+    int32_t active;         // slot holds a dialogue that still steps
+    uint64_t seed;          // Philox key
 };
 
-struct LoopState {          // one per engine, device resident (mirrored to pinned host memory)
-    int32_t step;           // decode steps executed so far (= generated rows)
-    int32_t done;           // all rows finished
-    int32_t base_length;    // T-7 (padded slots)
-    int32_t max_length;     // HF max_length in padded slots
-    int32_t tf_len;         // T
+struct LoopState {          // one per engine, device resident
+    int32_t step;           // decode steps executed so far by the engine
+    int32_t done;           // no active row is unfinished
+    int32_t continuous;     // 1: a finished row leaves the batch at once (scheduler); 0: it keeps emitting the
+                            //    reference's finished-row padding until the whole batch is done (mtts_generate)
     int32_t B;
-    int32_t error;          // sticky device-side error (e.g. candidate overflow)
-    int32_t pad;
+    int32_t error;          // sticky device-side error
+    int32_t gen_cap;        // rows of generated-token storage per slot
+    int32_t pad0, pad1;
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -102,20 +108,26 @@ struct SampleCtx {         // resolved per (row, channel)
     const uint32_t* bm;
     int V, mask_id, step, c;
     float penalty, temp;
+    uint64_t seed;
+    uint32_t row_id;
 };
 
 __device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const uint16_t* logits0,
                                            const uint16_t* logits17, int V0, int Vs, int Vs_pad,
                                            const uint32_t* bitmaps, int bm_words, const MttsSamplerCfg* cfgs,
-                                           const LoopState* ls, int single_vocab, int single_mask, int single_step,
-                                           int single_channel) {
+                                           const LoopState* ls, const SeqState* seqs, int single_vocab, int single_mask,
+                                           int single_step, int single_channel) {
     if (single_vocab > 0) {            // unit-test entry: one logits matrix [rows][vocab]
         x.c = single_channel; x.step = single_step; x.V = single_vocab; x.mask_id = single_mask;
+        x.seed = 0; x.row_id = (uint32_t)b;
         x.lg = logits0 + (size_t)b * x.V;
         x.bm = bitmaps ? bitmaps + (size_t)b * bm_words : nullptr;
     } else {
         if (ls->done) return false;
-        x.c = c_in; x.step = ls->step;
+        const SeqState sq = seqs[b];
+        if (!sq.active || !sq.unfinished) return false;     // its tokens are forced by the state machine anyway
+        x.c = c_in; x.step = sq.step;
+        x.seed = sq.seed; x.row_id = (uint32_t)sq.row_id;
         x.V = (x.c == 0) ? V0 : Vs;
         x.lg = (x.c == 0) ? logits0 + (size_t)b * V0 : logits17 + ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
         // modeling_asteroid.py:124-128 (hard-coded ids 1024 / 152694 as in the reference)
@@ -149,14 +161,15 @@ __device__ __forceinline__ void block_argmax(float& bv, int& bi, float* shf, int
 
 __global__ __launch_bounds__(SAMP_T) void sample_scan_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
-    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, SampleScratch sc, int single_vocab,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
+    SampleScratch sc, int single_vocab,
     int single_mask, int single_step, int single_channel) {
     __shared__ uint32_t hist[2048];
     __shared__ float shf[SAMP_T / 64];
     __shared__ int shi[SAMP_T / 64];
     const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
     SampleCtx x;
-    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, seqs, single_vocab, single_mask,
                     single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
     const bool want_hist = cfg.do_sample && cfg.top_k > 0 && cfg.top_k < x.V;
@@ -180,13 +193,14 @@ __global__ __launch_bounds__(SAMP_T) void sample_scan_kernel(
 
 __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
-    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, SampleScratch sc, int single_vocab,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
+    SampleScratch sc, int single_vocab,
     int single_mask, int single_step, int single_channel) {
     __shared__ uint32_t wsum[SAMP_T / 64];
     __shared__ int sh_b0;
     const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     SampleCtx x;
-    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, seqs, single_vocab, single_mask,
                     single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
     if (!cfg.do_sample) return;
@@ -341,8 +355,8 @@ __device__ int finish_sample(float* __restrict__ cval, int* __restrict__ cidx, i
 __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
     const uint16_t* __restrict__ logits0, const uint16_t* __restrict__ logits17, int V0, int Vs, int Vs_pad,
     const uint32_t* __restrict__ bitmaps, int bm_words, const MttsSamplerCfg* __restrict__ cfgs,
-    const LoopState* __restrict__ ls, uint64_t seed, int32_t* __restrict__ decisions, int32_t* __restrict__ err,
-    SampleScratch sc, int big_channel0, int single_vocab, int single_mask, int single_step, int single_channel) {
+    const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs, uint64_t seed, int32_t* __restrict__ decisions,
+    int32_t* __restrict__ err, SampleScratch sc, int big_channel0, int single_vocab, int single_mask, int single_step, int single_channel) {
     __shared__ float cval[SAMP_CAND];
     __shared__ int cidx[SAMP_CAND];
     __shared__ float shf[SAMP_T / 64];
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     SampleCtx x;
-    if (!sample_ctx(x, b, blockIdx.x, logits0, logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, single_vocab,
+    if (!sample_ctx(x, b, blockIdx.x, logits0, logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seqs, single_vocab,
                     single_mask, single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
     const bool big = single_vocab > 0 ? (single_vocab > SAMP_CAND) : (x.c == 0 && big_channel0);
@@ -397,7 +411,8 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
         if (tid == 0) { decisions[out_slot] = amax; if (n > SAMP_CAND) sc.overflow[b] = 1; }
         return;
     }
-    const int pick = finish_sample<SAMP_T>(cval, cidx, n, cfg, smax, (uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, seed, shd, sh_i);
+    const int pick = finish_sample<SAMP_T>(cval, cidx, n, cfg, smax, (uint32_t)x.step, x.row_id, (uint32_t)x.c,
+                                           single_vocab > 0 ? seed : x.seed, shd, sh_i);
     if (tid == 0) decisions[out_slot] = pick;
 }
 
@@ -406,8 +421,8 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
 #define SAMP_FT 1024
 __global__ __launch_bounds__(SAMP_FT) void sample_full_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
-    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, uint64_t seed,
-    int32_t* __restrict__ decisions, SampleScratch sc, int full_cap, int single_vocab, int single_mask, int single_step,
+    const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
+    uint64_t seed, int32_t* __restrict__ decisions, SampleScratch sc, int full_cap, int single_vocab, int single_mask, int single_step,
     int single_channel) {
     __shared__ float shf[SAMP_FT / 64];
     __shared__ double shd[SAMP_FT / 64];
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(SAMP_FT) void sample_full_kernel(
     const int b = blockIdx.x, tid = threadIdx.x;
     if (!sc.overflow[b]) return;
     SampleCtx x;
-    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, single_vocab, single_mask,
+    if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, seqs, single_vocab, single_mask,
                     single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
     float* val = sc.full_val + (size_t)b * full_cap;
@@ -436,150 +451,157 @@ __global__ __launch_bounds__(SAMP_FT) void sample_full_kernel(
     const int n = sh_i[0];
     __syncthreads();
     int pick = bi;
-    if (n > 0) pick = finish_sample<SAMP_FT>(val, idx, n, cfg, smax, (uint32_t)x.step, (uint32_t)b, (uint32_t)x.c, seed, shd, sh_i);
+    if (n > 0) pick = finish_sample<SAMP_FT>(val, idx, n, cfg, smax, (uint32_t)x.step, x.row_id, (uint32_t)x.c,
+                                            single_vocab > 0 ? seed : x.seed, shd, sh_i);
     if (tid == 0) { decisions[b * 8 + x.c] = pick; sc.overflow[b] = 0; }
 }
 
-// One block; thread b handles sequence b.  Restates modeling_asteroid.py:139-169.
-// gen: [max_steps][32][8] generated rows; tf_tail: [32][7][8] last 7 prompt slots
-// (tf_inputs[:, base_length + s, :]); forced: optional [max_steps][32][8] (-1 = none).
+// One block; thread b handles sequence slot b.  Restates modeling_asteroid.py:139-169 with a per-dialogue clock.
+// gen / dec_log / forced: [slot][gen_cap][8]; tf_tail: [slot][7][8] = tf_inputs[:, base_length + s, :].
 __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __restrict__ dec_log,
                               const int32_t* __restrict__ forced, const int32_t* __restrict__ tf_tail,
                               int32_t* __restrict__ gen, int32_t* __restrict__ cur_tokens,
                               SeqState* __restrict__ seqs, RowMeta* __restrict__ meta, uint32_t* __restrict__ bitmaps,
-                              int bm_words, LoopState* __restrict__ ls, LoopState* __restrict__ host_ls,
-                              int eos, int spad, int sp_lo, int sp_hi, int max_steps) {
+                              int bm_words, LoopState* __restrict__ ls, int eos, int spad, int sp_lo, int sp_hi) {
     __shared__ int any_unfinished;
     if (ls->done) return;
-    const int b = threadIdx.x, B = ls->B, step = ls->step;
+    const int b = threadIdx.x, B = ls->B;
+    const int cap = ls->gen_cap;
     if (b == 0) any_unfinished = 0;
     __syncthreads();
     if (b < B) {
         SeqState s = seqs[b];
-        int tok[8];
+        if (!s.active || s.step >= cap) {
+            meta[b].seq = -1;
+            if (s.active && s.step >= cap) { s.active = 0; s.unfinished = 0; seqs[b] = s; }
+        } else {
+            const int step = s.step;
+            int tok[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tok[c] = decisions[b * 8 + c];
-        // :140-141
-        const bool speech = tok[0] >= sp_lo && tok[0] < sp_hi;
-        if (!speech && s.nas < 0) s.nas = 7;
-        // :143-145 teacher forcing of the delayed prompt tail (first 7 steps)
-        if (step < 7) {
+            for (int c = 0; c < 8; ++c) tok[c] = s.unfinished ? decisions[b * 8 + c] : 0;
+            // :140-141
+            const bool speech = tok[0] >= sp_lo && tok[0] < sp_hi;
+            if (s.unfinished && !speech && s.nas < 0) s.nas = 7;
+            // :143-145 teacher forcing of the delayed prompt tail (first 7 steps)
+            if (step < 7) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c >= step + 1) tok[c] = tf_tail[(b * 7 + step) * 8 + c];
-        }
-        // :148-153 EOS flush
-        if (s.nas > 0 && s.nas < 7) {
-            tok[0] = eos;
+                for (int c = 0; c < 8; ++c)
+                    if (c >= step + 1) tok[c] = tf_tail[(b * 7 + step) * 8 + c];
+            }
+            // :148-153 EOS flush
+            if (s.nas > 0 && s.nas < 7) {
+                tok[0] = eos;
 #pragma unroll
-            for (int c = 1; c < 8; ++c)
-                if (s.nas < 8 - c) tok[c] = spad;
-        }
-        // :155-158 finished rows
-        if (!s.unfinished) {
-            tok[0] = eos;
+                for (int c = 1; c < 8; ++c)
+                    if (s.nas < 8 - c) tok[c] = spad;
+            }
+            // :155-158 finished rows
+            if (!s.unfinished) {
+                tok[0] = eos;
 #pragma unroll
-            for (int c = 1; c < 8; ++c) tok[c] = spad;
-        }
-        if (dec_log) {
+                for (int c = 1; c < 8; ++c) tok[c] = spad;
+            }
+            const size_t slot = ((size_t)b * cap + step) * 8;
+            if (dec_log) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) dec_log[((size_t)step * MTTS_RCAP + b) * 8 + c] = tok[c];
-        }
-        if (forced) {
+                for (int c = 0; c < 8; ++c) dec_log[slot + c] = tok[c];
+            }
+            if (forced) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    int f = forced[slot + c];
+                    if (f >= 0) tok[c] = f;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                int f = forced[((size_t)step * MTTS_RCAP + b) * 8 + c];
-                if (f >= 0) tok[c] = f;
+                gen[slot + c] = tok[c];
+                cur_tokens[b * 8 + c] = tok[c];
+                uint32_t* bm = bitmaps + ((size_t)b * 8 + c) * bm_words;
+                bm[tok[c] >> 5] |= 1u << (tok[c] & 31);       // history for the repetition penalty
             }
+            // :165-168
+            if (s.nas > 0) s.nas -= 1;
+            const int new_len = s.base_length + step + 1;
+            const bool stopping = (new_len >= s.max_length) || (tok[0] == eos) || (s.nas == 0);
+            s.unfinished = (s.unfinished && !stopping) ? 1 : 0;
+            if (s.nas > 0) s.unfinished = 1;
+            s.step = step + 1;
+            if (ls->continuous && !s.unfinished) s.active = 0;      // scheduler mode: the slot is free again
+            // the forward that follows appends this token to the cache at position kv_len
+            meta[b].seq = s.unfinished ? b : -1;
+            meta[b].pos = s.kv_len;
+            meta[b].last = 1;
+            s.kv_len += 1;
+            seqs[b] = s;
+            if (s.unfinished) atomicOr(&any_unfinished, 1);
         }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            gen[((size_t)step * MTTS_RCAP + b) * 8 + c] = tok[c];
-            cur_tokens[b * 8 + c] = tok[c];
-            uint32_t* bm = bitmaps + ((size_t)b * 8 + c) * bm_words;
-            bm[tok[c] >> 5] |= 1u << (tok[c] & 31);       // history for the repetition penalty
-        }
-        // :165-168
-        if (s.nas > 0) s.nas -= 1;
-        const int new_len = ls->base_length + step + 1;
-        const bool stopping = (new_len >= ls->max_length) || (tok[0] == eos) || (s.nas == 0);
-        s.unfinished = (s.unfinished && !stopping) ? 1 : 0;
-        if (s.nas > 0) s.unfinished = 1;
-        // the forward that follows appends this token to the cache at position kv_len
-        meta[b].seq = s.unfinished ? b : -1;
-        meta[b].pos = s.kv_len;
-        meta[b].last = 1;
-        s.kv_len += 1;
-        seqs[b] = s;
-        if (s.unfinished) atomicOr(&any_unfinished, 1);
     }
     __syncthreads();
     if (b == 0) {
-        ls->step = step + 1;
-        if (!any_unfinished || step + 1 >= max_steps) ls->done = 1;
-        if (host_ls) { host_ls->step = ls->step; host_ls->done = ls->done; host_ls->error = ls->error; }
+        ls->step = ls->step + 1;
+        if (!any_unfinished) ls->done = 1;
     }
 }
 
 static SampleScratch g_dummy_scratch;
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps, int bm_words,
-                   const MttsSamplerCfg* cfgs, const LoopState* ls, uint64_t seed, int32_t* decisions, int32_t* err,
-                   int B, const SampleScratch& sc, int ch0_sampled, int full_cap, hipStream_t st) {
+                   const MttsSamplerCfg* cfgs, const LoopState* ls, const SeqState* seqs, uint64_t seed, int32_t* decisions,
+                   int32_t* err, int B, const SampleScratch& sc, int ch0_sampled, int full_cap, hipStream_t st) {
     const int big0 = V0 > SAMP_CAND ? 1 : 0;
     if (big0) {
         hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
-                           bitmaps, bm_words, cfgs, ls, sc, 0, 0, 0, 0);
+                           bitmaps, bm_words, cfgs, ls, seqs, sc, 0, 0, 0, 0);
         if (ch0_sampled)
             hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
-                               bitmaps, bm_words, cfgs, ls, sc, 0, 0, 0, 0);
+                               bitmaps, bm_words, cfgs, ls, seqs, sc, 0, 0, 0, 0);
     }
     hipLaunchKernelGGL(sample_final_kernel, dim3(8, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0,
-                       (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seed, decisions, err, sc,
+                       (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seqs, seed, decisions, err, sc,
                        big0, 0, 0, 0, 0);
     if (big0 && ch0_sampled)
         hipLaunchKernelGGL(sample_full_kernel, dim3(B), dim3(SAMP_FT), 0, st, (const uint16_t*)logits0, V0, bitmaps,
-                           bm_words, cfgs, ls, seed, decisions, sc, full_cap, 0, 0, 0, 0);
+                           bm_words, cfgs, ls, seqs, seed, decisions, sc, full_cap, 0, 0, 0, 0);
 }
 void launch_sample_single(const void* logits, int rows, int vocab, const uint32_t* bitmap, int bm_words,
                           const MttsSamplerCfg* cfgs8, int mask_id, uint64_t seed, int step, int channel,
                           int32_t* decisions, int32_t* err, const SampleScratch& sc, int full_cap, hipStream_t st) {
     if (vocab > SAMP_CAND) {
         hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
-                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, sc, vocab, mask_id, step, channel);
+                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, sc, vocab, mask_id, step, channel);
         hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
-                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, sc, vocab, mask_id, step, channel);
+                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, sc, vocab, mask_id, step, channel);
     }
     hipLaunchKernelGGL(sample_final_kernel, dim3(1, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits,
                        (const uint16_t*)nullptr, vocab, vocab, vocab, bitmap, bm_words, cfgs8, (const LoopState*)nullptr,
-                       seed, decisions, err, sc, 1, vocab, mask_id, step, channel);
+                       (const SeqState*)nullptr, seed, decisions, err, sc, 1, vocab, mask_id, step, channel);
     if (vocab > SAMP_CAND)
         hipLaunchKernelGGL(sample_full_kernel, dim3(rows), dim3(SAMP_FT), 0, st, (const uint16_t*)logits, vocab, bitmap,
-                           bm_words, cfgs8, (const LoopState*)nullptr, seed, decisions, sc, full_cap, vocab, mask_id, step,
-                           channel);
+                           bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, seed, decisions, sc, full_cap, vocab,
+                           mask_id, step, channel);
 }
 void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* forced, const int32_t* tf_tail,
                    int32_t* gen, int32_t* cur_tokens, SeqState* seqs, RowMeta* meta, uint32_t* bitmaps, int bm_words,
-                   LoopState* ls, LoopState* host_ls, int eos, int spad, int sp_lo, int sp_hi, int max_steps,
-                   hipStream_t st) {
+                   LoopState* ls, int eos, int spad, int sp_lo, int sp_hi, hipStream_t st) {
     hipLaunchKernelGGL(update_kernel, dim3(1), dim3(MTTS_RCAP), 0, st, decisions, dec_log, forced, tf_tail, gen,
-                       cur_tokens, seqs, meta, bitmaps, bm_words, ls, host_ls, eos, spad, sp_lo, sp_hi, max_steps);
+                       cur_tokens, seqs, meta, bitmaps, bm_words, ls, eos, spad, sp_lo, sp_hi);
 }
 
 // Un-shift the delay pattern on the device (reference generation_utils.py:416-425):
 // codes[c][b][f - first] = gen[f + c][b][c] (- speech offset on channel 0), frames first..first+n-1.
 __global__ void export_codes_kernel(const int32_t* __restrict__ gen, int64_t* __restrict__ codes, int B, int first, int n,
-                                    int speech_offset, int clamp_hi) {
+                                    int speech_offset, int clamp_hi, int cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 8 * B * n) return;
     const int t = i % n, b = (i / n) % B, c = i / (n * B);
-    int v = gen[((size_t)(first + t + c) * MTTS_RCAP + b) * 8 + c];
+    int v = gen[((size_t)b * cap + (first + t + c)) * 8 + c];
     if (c == 0) v -= speech_offset;
     v = min(max(v, 0), clamp_hi);          // flushed / padded frames carry 1024 or EOS: keep the gather in range
     codes[i] = v;
 }
 void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
-                         hipStream_t st) {
+                         int cap, hipStream_t st) {
     int total = 8 * B * n;
     hipLaunchKernelGGL(export_codes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, gen, codes, B, first, n,
-                       speech_offset, clamp_hi);
+                       speech_offset, clamp_hi, cap);
 }

@@ -55,6 +55,10 @@ _SIGS = {
     "mtts_sync_state": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "mtts_read_generated": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mtts_read_logits": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_sched_open": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(MttsSamplerCfg), C.c_void_p]),
+    "mtts_slot_submit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
+    "mtts_slot_states": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_slot_read": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mtts_read_seq_state": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_export_codes": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mtts_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),

@@ -147,6 +147,30 @@ class Engine:
         f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
         return f(l0), f(l17)
 
+    # ---- continuous batching ---------------------------------------------------------
+    def sched_open(self, slots, gen_cap, layers=None, do_samples=None):
+        self._B = int(slots)
+        capi.check(self.lib.mtts_sched_open(self._h, int(slots), int(gen_cap), sampler_cfgs(layers, do_samples), None))
+
+    def submit(self, slot, ids, max_length, seed=0):
+        """ids int64 [T,8]: one delay-shifted prompt without padding (what shifting_inputs returns)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        assert ids.ndim == 2 and ids.shape[1] == 8
+        capi.check(self.lib.mtts_slot_submit(self._h, int(slot), ids.ctypes.data, ids.shape[0], int(max_length),
+                                             C.c_uint64(seed), None))
+
+    def slot_states(self):
+        """-> int32 [slots,4]: active, unfinished, rows generated, tokens cached."""
+        st = np.zeros((self._B, 4), dtype=np.int32)
+        capi.check(self.lib.mtts_slot_states(self._h, st.ctypes.data, None))
+        return st
+
+    def slot_read(self, slot, capacity):
+        buf = np.zeros((int(capacity), 8), dtype=np.int64)
+        n = C.c_int32(0)
+        capi.check(self.lib.mtts_slot_read(self._h, int(slot), buf.ctypes.data, int(capacity), C.byref(n)))
+        return buf[:n.value].copy()
+
     def seq_state(self):
         """-> (needs_additional_steps[B], unfinished[B], kv_len[B]) numpy int32."""
         a, u, k = (np.zeros(self._B, dtype=np.int32) for _ in range(3))
