@@ -609,6 +609,8 @@ static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
 
 static int ensure_workspace(MttsCodec* k, int B, int T) {
     if (B <= k->cap_B && T <= k->cap_T) return 0;
+    B = std::max(B, k->cap_B);            // never shrink one dimension while growing the other
+    T = std::max(T, k->cap_T);
     const MttsCodecConfig& c = k->c;
     float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->bufE, k->big, k->scores, k->melbuf, k->melmax};
     for (float* p : bufs) if (p) hipFree(p);
