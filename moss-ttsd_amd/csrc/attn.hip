@@ -22,9 +22,8 @@ template <int G>
 __global__ __launch_bounds__(256) void attn_scores_kernel(
     const uint16_t* __restrict__ qbuf, const u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
     const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
-    int total_pages, int nq, int nkv, float scale, const int32_t* __restrict__ done) {
+    int total_pages, int nq, int nkv, float scale) {
     __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
-    if (done && *done) return;
     const int r = blockIdx.z, kvh = blockIdx.y;
     const RowMeta m = meta[r];
     if (m.seq < 0) return;
@@ -91,10 +90,9 @@ template <int G>
 __global__ __launch_bounds__(256) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, const u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
-    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, const int32_t* __restrict__ done) {
+    int max_pages, int total_pages, int nchunks_max, int nq, int nkv) {
     __shared__ float red[4][G][MTTS_HD];
     __shared__ uint16_t pbuf[4][G][MTTS_PAGE];
-    if (done && *done) return;
     const int r = blockIdx.z, kvh = blockIdx.y, chunk = blockIdx.x;
     const RowMeta m = meta[r];
     if (m.seq < 0) return;
@@ -185,19 +183,23 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     }
 }
 
-// grid = (R, nq), block 128
+// grid = (R, nq), block 128.  The chunk partials are loaded 8 at a time (independent loads; a loop that adds as it
+// loads would pay one memory round trip per chunk) and summed in chunk order.
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ opart, const RowMeta* __restrict__ meta,
-                                                           uint16_t* __restrict__ out_packed, int nchunks_max, int nq,
-                                                           const int32_t* __restrict__ done) {
-    if (done && *done) return;
+                                                           uint16_t* __restrict__ out_packed, int nchunks_max, int nq) {
     const int r = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
     const RowMeta m = meta[r];
     float s = 0.f;
-    if (m.seq >= 0) {
-        const int npages = (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE;
-        const int nch = (npages + ATT_PB - 1) / ATT_PB;
-        const float* p = opart + ((size_t)r * nq + h) * nchunks_max * MTTS_HD + d;
-        for (int c = 0; c < nch; ++c) s += p[(size_t)c * MTTS_HD];
+    const int npages = m.seq >= 0 ? (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE : 0;
+    const int nch = (npages + ATT_PB - 1) / ATT_PB;
+    const float* p = opart + ((size_t)r * nq + h) * nchunks_max * MTTS_HD + d;
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = p[(size_t)min(c0 + j, nch - 1) * MTTS_HD];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < nch) s += t[j];
     }
     out_packed[xpack_off(r, h * MTTS_HD + d, nq * MTTS_HD)] = f2bf(s);
 }
@@ -207,19 +209,20 @@ static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcac
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                           int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                           const int32_t* done, int phase, hipStream_t st) {
+    (void)done;   // rows that are not running carry seq < 0 in their RowMeta
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
         hipLaunchKernelGGL((attn_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
-                           page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, done);
+                           page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale);
     }
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
         hipLaunchKernelGGL((attn_pv_kernel<G>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
-                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, done);
+                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv);
     }
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
-                           (uint16_t*)out_packed, nchunks_max, nq, done);
+                           (uint16_t*)out_packed, nchunks_max, nq);
 }
 
 int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -141,6 +142,11 @@ struct MttsEngine {
     int max_real = 0;
     uint64_t seed = 0;
     bool began = false, has_forced = false;
+    // decode-step graphs: one captured step per (rows, KV page bound, ...) key, replayed by mtts_step
+    struct StepGraph { int B, pages, forced, ch0; uint64_t seed; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
+    hipStream_t cap_stream = nullptr;
+    bool use_graphs = true;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_N];
@@ -202,6 +208,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     MttsEngine* e = new MttsEngine();
     e->cfg = *c;
     e->device = device;
+    if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
     e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
     e->V0 = c->vocab_size; e->Vs = c->speech_vocab_size;
@@ -277,6 +284,11 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     return MTTS_OK;
 }
 
+static void drop_graphs(MttsEngine* e) {
+    for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
+
 int32_t mtts_engine_destroy(MttsEngine* e) {
     if (!e) return MTTS_OK;
     hipSetDevice(e->device);
@@ -294,6 +306,8 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_ls) hipHostFree(e->h_ls);
     free_scratch(e->sscr);
+    drop_graphs(e);
+    if (e->cap_stream) hipStreamDestroy(e->cap_stream);
     for (int w = 0; w < PROF_N; ++w) for (auto& pr : e->ev[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete e;
     return MTTS_OK;
@@ -307,6 +321,7 @@ static bool ends_with(const std::string& s, const char* suf) {
 int32_t mtts_bind_weight(MttsEngine* e, const char* name_c, const void* src, int64_t rows, int64_t cols, void* stream) {
     if (!e || !name_c || !src) return fail(MTTS_EINVAL, "null argument");
     HIPCHK(hipSetDevice(e->device));
+    drop_graphs(e);
     hipStream_t st = S(stream);
     std::string name(name_c);
     const int H = e->H, I = e->I, D = MTTS_HD;
@@ -371,6 +386,7 @@ int32_t mtts_bind_weight(MttsEngine* e, const char* name_c, const void* src, int
 int32_t mtts_bind_rope(MttsEngine* e, const void* cosb, const void* sinb, int32_t rows, void* stream) {
     if (!e || !cosb || !sinb || rows < 1) return fail(MTTS_EINVAL, "bad rope table");
     HIPCHK(hipSetDevice(e->device));
+    drop_graphs(e);
     if (e->rope_cos) { hipFree(e->rope_cos); hipFree(e->rope_sin); }
     TRY(dalloc((uint16_t**)&e->rope_cos, (size_t)rows * 64, false));
     TRY(dalloc((uint16_t**)&e->rope_sin, (size_t)rows * 64, false));
@@ -461,6 +477,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
 static int ensure_gen_storage(MttsEngine* e, int steps) {
     if (steps <= e->gen_cap) return 0;
     if (e->d_gen) { hipFree(e->d_gen); hipFree(e->d_declog); hipFree(e->d_forced); }
+    drop_graphs(e);                      // captured steps hold the old pointers
     e->gen_cap = steps;
     const size_t n = (size_t)e->cfg.max_batch * steps * 8;
     TRY(dalloc(&e->d_gen, n));
@@ -582,24 +599,64 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     return MTTS_OK;
 }
 
+// One decode step: sample from the previous logits, advance the per-dialogue state machine, run the stack.
+// Nothing in it depends on the host (step counters, lengths and the stop flag live on the device), so the same
+// launches repeat until the KV page bound grows: they are captured once per bound into a hipGraph and replayed --
+// a dependent kernel costs ~1.5 us inside a graph against ~2.9 us launched on a stream (tools/latency_probe.hip).
+static int step_body(MttsEngine* e, int pages_bound, hipStream_t st, int64_t kvtok) {
+    launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
+                  e->d_seqs, e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled,
+                  full_cap_for(e->V0), st);
+    launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
+                  e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, e->cfg.eos_token_id,
+                  e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, st);
+    return forward_rows(e, e->d_cur, e->d_meta, round_up(e->B, 32), pages_bound, 1, &e->d_ls->done, st, kvtok);
+}
+
+static int step_graph(MttsEngine* e, int pages, hipGraphExec_t* out) {
+    const int forced = e->has_forced ? 1 : 0;
+    for (auto& g : e->graphs)
+        if (g.B == e->B && g.pages == pages && g.forced == forced && g.ch0 == e->ch0_sampled && g.seed == e->seed) {
+            *out = g.exec;
+            return MTTS_OK;
+        }
+    if (e->graphs.size() >= 256) drop_graphs(e);
+    if (!e->cap_stream) HIPCHK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+    int rc = step_body(e, pages, e->cap_stream, 0);
+    hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    HIPCHK(ce);
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    HIPCHK(ie);
+    e->graphs.push_back({e->B, pages, forced, e->ch0_sampled, e->seed, exec});
+    *out = exec;
+    return MTTS_OK;
+}
+
 static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
         if (e->steps_issued >= e->max_steps) break;
-        hipEvent_t ev = nullptr;
-        prof_begin(e, PROF_STEP, st, &ev);
-        launch_sample(e->logits0, e->logits17, e->V0, e->Vs, e->Vs_pad, e->d_bitmaps, e->bm_words, e->d_scfg, e->d_ls,
-                      e->d_seqs, e->seed, e->d_decisions, &e->d_ls->error, e->B, e->sscr, e->ch0_sampled,
-                      full_cap_for(e->V0), st);
-        launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
-                      e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, e->cfg.eos_token_id,
-                      e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, st);
         const int len_bound = e->max_real + e->steps_issued + 1;
         const int pages_bound = (len_bound + MTTS_PAGE - 1) / MTTS_PAGE;
-        // rough KV token count for the profile's byte figure: every row at its current length
-        int64_t kvtok = 0;
-        for (int b = 0; b < e->B; ++b) kvtok += e->n_real[b] + e->steps_issued + 1;
-        TRY(forward_rows(e, e->d_cur, e->d_meta, round_up(e->B, 32), pages_bound, 1, &e->d_ls->done, st, kvtok));
-        prof_end(e, st, ev);
+        if (e->use_graphs && !e->prof) {
+            // the attention grids are sized by the page bound: round it up to a whole pass-B chunk so that one
+            // graph serves ATT_PB pages (512 steps); blocks past a row's last page exit at once
+            hipGraphExec_t exec = nullptr;
+            TRY(step_graph(e, std::min(round_up(pages_bound, ATT_PB), e->max_pages), &exec));
+            HIPCHK(hipGraphLaunch(exec, st));
+        } else {
+            hipEvent_t ev = nullptr;
+            prof_begin(e, PROF_STEP, st, &ev);
+            // rough KV token count for the profile's byte figure: every row at its current length
+            int64_t kvtok = 0;
+            for (int b = 0; b < e->B; ++b) kvtok += e->n_real[b] + e->steps_issued + 1;
+            TRY(step_body(e, pages_bound, st, kvtok));
+            prof_end(e, st, ev);
+        }
         e->steps_issued++;
     }
     return MTTS_OK;

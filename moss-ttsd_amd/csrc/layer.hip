@@ -23,31 +23,58 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 __global__ __launch_bounds__(256) void embed_norm_kernel(
     const int32_t* __restrict__ tokens /*[R][8]*/, const RowMeta* __restrict__ meta,
     const uint16_t* const* __restrict__ tables /*[8]*/, const uint16_t* __restrict__ norm_w,
-    uint16_t* __restrict__ x, uint16_t* __restrict__ xn_packed, int H, float eps, const int32_t* __restrict__ done) {
+    uint16_t* __restrict__ x, uint16_t* __restrict__ xn_packed, int H, float eps) {
     __shared__ float sh[4];
-    if (done && *done) return;
     const int r = blockIdx.x;
     const bool active = meta[r].seq >= 0;
-    float ss = 0.f;
-    // each thread owns elements i = threadIdx.x + 256*j
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float acc = 0.f;
-        if (active) {
+    // the 8 row addresses are block-uniform; each thread then owns 8 consecutive elements per 2048-wide chunk,
+    // so the gather is 8 independent 16-byte loads in flight (one per channel), summed in channel order
+    const uint16_t* row[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                int t = tokens[r * 8 + c];
-                acc = rbf(acc + bf2f(tables[c][(size_t)t * H + i]));
+    for (int c = 0; c < 8; ++c) row[c] = tables[c] + (size_t)(active ? tokens[r * 8 + c] : 0) * H;
+    constexpr int MAXC = 4;                       // H <= 8192
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < MAXC; ++cc) {
+        const int i0 = cc * 2048 + threadIdx.x * 8;
+        if (i0 < H) {
+            u32x4_t e[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) e[c] = *(const u32x4_t*)(row[c] + i0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[cc][j] = 0.f;
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v[cc][0] = rbf(v[cc][0] + bflo(e[c].x)); v[cc][1] = rbf(v[cc][1] + bfhi(e[c].x));
+                    v[cc][2] = rbf(v[cc][2] + bflo(e[c].y)); v[cc][3] = rbf(v[cc][3] + bfhi(e[c].y));
+                    v[cc][4] = rbf(v[cc][4] + bflo(e[c].z)); v[cc][5] = rbf(v[cc][5] + bfhi(e[c].z));
+                    v[cc][6] = rbf(v[cc][6] + bflo(e[c].w)); v[cc][7] = rbf(v[cc][7] + bfhi(e[c].w));
+                }
             }
+            u32x4_t xo;
+            xo.x = pack2(v[cc][0], v[cc][1]); xo.y = pack2(v[cc][2], v[cc][3]);
+            xo.z = pack2(v[cc][4], v[cc][5]); xo.w = pack2(v[cc][6], v[cc][7]);
+            *(u32x4_t*)(x + (size_t)r * H + i0) = xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[cc][j] * v[cc][j];
         }
-        x[(size_t)r * H + i] = f2bf(acc);
-        ss += acc * acc;
     }
     float tot = block_sum_256(ss, sh);
     float inv = 1.0f / sqrtf(tot / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float v = bf2f(x[(size_t)r * H + i]);
-        float y = rbf(bf2f(norm_w[i]) * rbf(v * inv));
-        xn_packed[xpack_off(r, i, H)] = f2bf(y);
+#pragma unroll
+    for (int cc = 0; cc < MAXC; ++cc) {
+        const int i0 = cc * 2048 + threadIdx.x * 8;
+        if (i0 < H) {
+            const u32x4_t w = *(const u32x4_t*)(norm_w + i0);
+            u32x4_t y;
+            y.x = pack2(bflo(w.x) * rbf(v[cc][0] * inv), bfhi(w.x) * rbf(v[cc][1] * inv));
+            y.y = pack2(bflo(w.y) * rbf(v[cc][2] * inv), bfhi(w.y) * rbf(v[cc][3] * inv));
+            y.z = pack2(bflo(w.z) * rbf(v[cc][4] * inv), bfhi(w.z) * rbf(v[cc][5] * inv));
+            y.w = pack2(bflo(w.w) * rbf(v[cc][6] * inv), bfhi(w.w) * rbf(v[cc][7] * inv));
+            *(u32x4_t*)(xn_packed + xpack_off(r, i0, H)) = y;
+        }
     }
 }
 
@@ -63,10 +90,10 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(
 __global__ __launch_bounds__(256) void resid_norm_kernel(
     const float* __restrict__ partial, int ksplit, int Npad, uint16_t* __restrict__ x,
     const uint16_t* __restrict__ norm_w, uint16_t* __restrict__ xn_packed, uint16_t* __restrict__ hlast,
-    const RowMeta* __restrict__ meta, int H, float eps, const int32_t* __restrict__ done) {
+    const RowMeta* __restrict__ meta, int H, float eps) {
     __shared__ float sh[4];
-    if (done && *done) return;
     const int r = blockIdx.x;
+    const size_t kstride = (size_t)MTTS_RCAP * Npad;
     // each thread owns 8 consecutive elements per 2048-wide chunk (16-byte loads/stores; the 8
     // elements are one 16-byte group of the X-fragment layout); values stay in registers.
     constexpr int MAXC = 4;                       // H <= 8192
@@ -77,14 +104,26 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
         const int i0 = c * 2048 + threadIdx.x * 8;
         if (i0 < H) {
             const float* p0 = partial + (size_t)r * Npad + i0;
-            float4 a = *(const float4*)p0, b = *(const float4*)(p0 + 4);
-            for (int k = 1; k < ksplit; ++k) {
-                const float* pk = partial + ((size_t)k * MTTS_RCAP + r) * Npad + i0;
-                float4 a2 = *(const float4*)pk, b2 = *(const float4*)(pk + 4);
-                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-                b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
-            }
             const u32x4_t xo = *(const u32x4_t*)(x + (size_t)r * H + i0);
+            // split-K slabs: up to 8 x 32 bytes per thread in flight at once (a data-dependent loop would pay
+            // one memory round trip per slab); the sum keeps the fixed order k = 0, 1, 2, ...
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            for (int k0 = 0; k0 < ksplit; k0 += 8) {
+                float4 ta[8], tb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* pk = p0 + (size_t)min(k0 + j, ksplit - 1) * kstride;
+                    ta[j] = *(const float4*)pk;
+                    tb[j] = *(const float4*)(pk + 4);
+                }
+                if (k0 == 0) { a = ta[0]; b = tb[0]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j < ksplit && k0 + j > 0) {
+                        a.x += ta[j].x; a.y += ta[j].y; a.z += ta[j].z; a.w += ta[j].w;
+                        b.x += tb[j].x; b.y += tb[j].y; b.z += tb[j].z; b.w += tb[j].w;
+                    }
+            }
             v[c][0] = rbf(bflo(xo.x) + rbf(a.x)); v[c][1] = rbf(bfhi(xo.x) + rbf(a.y));
             v[c][2] = rbf(bflo(xo.y) + rbf(a.z)); v[c][3] = rbf(bfhi(xo.y) + rbf(a.w));
             v[c][4] = rbf(bflo(xo.z) + rbf(b.x)); v[c][5] = rbf(bfhi(xo.z) + rbf(b.y));
@@ -131,22 +170,36 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
     const uint16_t* __restrict__ rope_cos, const uint16_t* __restrict__ rope_sin,
     uint16_t* __restrict__ qbuf /*[R][nq][128]*/, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
-    const int32_t* __restrict__ page_table, int max_pages, int total_pages, int nq, int nkv, float eps,
-    const int32_t* __restrict__ done) {
-    if (done && *done) return;
+    const int32_t* __restrict__ page_table, int max_pages, int total_pages, int nq, int nkv, float eps) {
     const int r = blockIdx.x, h = blockIdx.y, l = threadIdx.x;
-    const RowMeta m = meta[r];
-    if (m.seq < 0) return;
     const int col = h * MTTS_HD;
-    float a = partial[(size_t)r * Npad + col + l];
-    float b = partial[(size_t)r * Npad + col + l + 64];
-    for (int k = 1; k < ksplit; ++k) {
-        a += partial[((size_t)k * MTTS_RCAP + r) * Npad + col + l];
-        b += partial[((size_t)k * MTTS_RCAP + r) * Npad + col + l + 64];
+    const size_t kstride = (size_t)MTTS_RCAP * Npad;
+    const float* p0 = partial + (size_t)r * Npad + col + l;
+    // all loads go out before anything is waited for: the split-K slabs (fixed summation order), then the
+    // row's position -> page / RoPE row.  Idle rows (seq < 0) run on clamped indices and store nothing.
+    float a = 0.f, b = 0.f;
+    const RowMeta m = meta[r];
+    const bool live = m.seq >= 0;
+    const int pos = live ? m.pos : 0;
+    const int page = page_table[(size_t)(live ? m.seq : 0) * max_pages + (pos >> 6)];
+    const float c = bf2f(rope_cos[(size_t)pos * 64 + l]);
+    const float s = bf2f(rope_sin[(size_t)pos * 64 + l]);
+    for (int k0 = 0; k0 < ksplit; k0 += 8) {
+        float ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* pk = p0 + (size_t)min(k0 + j, ksplit - 1) * kstride;
+            ta[j] = pk[0];
+            tb[j] = pk[64];
+        }
+        if (k0 == 0) { a = ta[0]; b = tb[0]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < ksplit && k0 + j > 0) { a += ta[j]; b += tb[j]; }
     }
     a = rbf(a);
     b = rbf(b);
-    const int page = page_table[(size_t)m.seq * max_pages + (m.pos >> 6)];
+    if (!live) return;
     const int tok = m.pos & 63;
     if (h >= nq + nkv) {   // V head: no norm, no rope
         const int kvh = h - nq - nkv;
@@ -161,8 +214,6 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     float inv = 1.0f / sqrtf(ss / (float)MTTS_HD + eps);
     a = rbf(bf2f(nw[l]) * rbf(a * inv));
     b = rbf(bf2f(nw[l + 64]) * rbf(b * inv));
-    const float c = bf2f(rope_cos[(size_t)m.pos * 64 + l]);
-    const float s = bf2f(rope_sin[(size_t)m.pos * 64 + l]);
     // q_embed = q*cos + rotate_half(q)*sin ; rotate_half = cat(-x2, x1)
     float o1 = rbf(rbf(a * c) + rbf(-b * s));
     float o2 = rbf(rbf(b * c) + rbf(a * s));
@@ -199,13 +250,14 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t* __res
 
 void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
                        void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st) {
+    (void)done;   // rows that are not running carry seq < 0 in their RowMeta: no separate stop flag is read
     hipLaunchKernelGGL(embed_norm_kernel, dim3(R), dim3(256), 0, st, tokens, meta, tables, (const uint16_t*)norm_w,
-                       (uint16_t*)x, (uint16_t*)xn_packed, H, eps, done);
+                       (uint16_t*)x, (uint16_t*)xn_packed, H, eps);
 }
 void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, const void* norm_w, void* xn_packed,
                        void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st) {
     hipLaunchKernelGGL(resid_norm_kernel, dim3(R), dim3(256), 0, st, partial, ksplit, Npad, (uint16_t*)x,
-                       (const uint16_t*)norm_w, (uint16_t*)xn_packed, (uint16_t*)hlast, meta, H, eps, done);
+                       (const uint16_t*)norm_w, (uint16_t*)xn_packed, (uint16_t*)hlast, meta, H, eps);
 }
 void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
@@ -213,7 +265,8 @@ void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* 
                      const int32_t* done, hipStream_t st) {
     hipLaunchKernelGGL(qkv_post_kernel, dim3(R, nq + 2 * nkv), dim3(64), 0, st, partial, ksplit, Npad, meta,
                        (const uint16_t*)qnw, (const uint16_t*)knw, (const uint16_t*)cosb, (const uint16_t*)sinb,
-                       (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, total_pages, nq, nkv, eps, done);
+                       (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, total_pages, nq, nkv, eps);
+    (void)done;
 }
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w,
