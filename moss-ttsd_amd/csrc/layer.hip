@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
     // elements are one 16-byte group of the X-fragment layout); values stay in registers.
     constexpr int MAXC = 4;                       // H <= 8192
     float v[MAXC][8];
+    u32x4_t nw[MAXC];                             // norm weights: loaded with everything else, used after the sum
+    const RowMeta m = meta[r];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
         if (i0 < H) {
             const float* p0 = partial + (size_t)r * Npad + i0;
             const u32x4_t xo = *(const u32x4_t*)(x + (size_t)r * H + i0);
+            nw[c] = *(const u32x4_t*)(norm_w + i0);
             // split-K slabs: up to 8 x 32 bytes per thread in flight at once (a data-dependent loop would pay
             // one memory round trip per slab); the sum keeps the fixed order k = 0, 1, 2, ...
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -138,12 +141,11 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
     }
     float tot = block_sum_256(ss, sh);
     float inv = 1.0f / sqrtf(tot / (float)H + eps);
-    const RowMeta m = meta[r];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int i0 = c * 2048 + threadIdx.x * 8;
         if (i0 < H) {
-            const u32x4_t w = *(const u32x4_t*)(norm_w + i0);
+            const u32x4_t w = nw[c];
             u32x4_t y;
             y.x = pack2(bflo(w.x) * rbf(v[c][0] * inv), bfhi(w.x) * rbf(v[c][1] * inv));
             y.y = pack2(bflo(w.y) * rbf(v[c][2] * inv), bfhi(w.y) * rbf(v[c][3] * inv));

@@ -191,6 +191,37 @@ __global__ __launch_bounds__(SAMP_T) void sample_scan_kernel(
             if (hist[i]) atomicAdd(&sc.hist[(size_t)b * 2048 + i], hist[i]);
 }
 
+// Bin of the k-th largest score in a 2048-bin histogram of fkey(score) >> 21 (LDS or global), SAMP_T threads:
+// thread t owns bins 8t..8t+7; suffix sums over lanes and waves locate the bin.  Result in every thread.
+__device__ __forceinline__ int topk_bin(const uint32_t* hist, uint32_t k, uint32_t* wsum, int* sh_b0) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t* h = hist + tid * 8;
+    uint32_t cnt[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cnt[j] = h[j]; mine += cnt[j]; }
+    uint32_t suf = mine;                      // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    if (lane == 0) wsum[wid] = suf;
+    if (tid == 0) *sh_b0 = 0;
+    __syncthreads();
+    uint32_t above_waves = 0;
+    for (int w = wid + 1; w < SAMP_T / 64; ++w) above_waves += wsum[w];
+    const uint32_t above = above_waves + suf - mine;      // scores in bins strictly above this thread's
+    if (above < k && above + mine >= k) {
+        uint32_t run = above;
+        for (int j = 7; j >= 0; --j) {
+            run += cnt[j];
+            if (run >= k) { *sh_b0 = tid * 8 + j; break; }
+        }
+    }
+    __syncthreads();
+    return *sh_b0;
+}
+
 __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
     const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
@@ -206,33 +237,7 @@ __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
     if (!cfg.do_sample) return;
     int b0 = 0;                                   // no top-k: every finite score is a candidate
     if (cfg.top_k > 0 && cfg.top_k < x.V) {
-        // thread t owns bins 8t..8t+7; suffix sums locate the bin of the k-th largest score
-        const uint32_t* h = sc.hist + (size_t)b * 2048 + tid * 8;
-        uint32_t cnt[8], mine = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { cnt[j] = h[j]; mine += cnt[j]; }
-        uint32_t suf = mine;                      // inclusive suffix sum over lanes >= lane
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_down(suf, o, 64);
-            if (lane + o < 64) suf += t;
-        }
-        if (lane == 0) wsum[wid] = suf;
-        if (tid == 0) sh_b0 = 0;
-        __syncthreads();
-        uint32_t above_waves = 0;
-        for (int w = wid + 1; w < SAMP_T / 64; ++w) above_waves += wsum[w];
-        const uint32_t above = above_waves + suf - mine;      // scores in bins strictly above this thread's
-        const uint32_t k = (uint32_t)cfg.top_k;
-        if (above < k && above + mine >= k) {
-            uint32_t run = above;
-            for (int j = 7; j >= 0; --j) {
-                run += cnt[j];
-                if (run >= k) { sh_b0 = tid * 8 + j; break; }
-            }
-        }
-        __syncthreads();
-        b0 = sh_b0;
+        b0 = topk_bin(sc.hist + (size_t)b * 2048, (uint32_t)cfg.top_k, wsum, &sh_b0);
     }
     const uint32_t ninf_key = fkey(-INFINITY);
     const int per = (x.V + SAMP_NS - 1) / SAMP_NS;
@@ -363,6 +368,8 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
     __shared__ double shd[SAMP_T / 64];
     __shared__ int shi[SAMP_T / 64];
     __shared__ int sh_i[4];
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[SAMP_T / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     SampleCtx x;
@@ -388,15 +395,35 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
         for (int i = tid; i < 2048; i += SAMP_T) sc.hist[(size_t)b * 2048 + i] = 0;
         if (tid == 0) sc.cand_n[b] = 0;
     } else {
+        // small vocabulary (channels 1..7): scores straight from the logits.  With top_k set, an LDS histogram
+        // first finds the radix bin of the k-th largest score and only that bin and the ones above it are kept
+        // (a superset of the top-k set, typically ~2k entries): the sort below then runs on 64-128 slots, not 2048.
         float bv = -INFINITY; int bi = 0x7fffffff;
+        const bool prefilter = cfg.do_sample && cfg.top_k > 0 && cfg.top_k < x.V;
         if (tid == 0) sh_i[0] = 0;
+        if (prefilter)
+            for (int i = tid; i < 2048; i += SAMP_T) hist[i] = 0;
         __syncthreads();
         for (int i = tid; i < x.V; i += SAMP_T) {
             float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
             argmax_merge(bv, bi, s, i);
-            if (cfg.do_sample && s > -INFINITY) {
+            if (prefilter) atomicAdd(&hist[fkey(s) >> 21], 1u);
+            else if (cfg.do_sample && s > -INFINITY) {
                 int slot = atomicAdd(&sh_i[0], 1);
                 if (slot < SAMP_CAND) { cval[slot] = s; cidx[slot] = i; }
+            }
+        }
+        if (prefilter) {
+            __syncthreads();
+            const int b0 = topk_bin(hist, (uint32_t)cfg.top_k, wsum, &sh_i[2]);
+            const uint32_t ninf_key = fkey(-INFINITY);
+            for (int i = tid; i < x.V; i += SAMP_T) {
+                float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
+                uint32_t key = fkey(s);
+                if ((int)(key >> 21) >= b0 && key > ninf_key) {
+                    int slot = atomicAdd(&sh_i[0], 1);
+                    if (slot < SAMP_CAND) { cval[slot] = s; cidx[slot] = i; }
+                }
             }
         }
         block_argmax(bv, bi, shf, shi);

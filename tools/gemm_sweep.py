@@ -21,4 +21,4 @@ for name, N, K, epi in shapes:
                 continue
             res.append((us.value, ks, wv))
     res.sort()
-    print(name, f"{mb:.1f} MB", " | ".join(f"ks{k} w{w}: {u:.1f}us {mb / u * 1e-3 * 1e3:.0f}GB/s" for u, k, w in res[:6]), flush=True)
+    print(name, f"{mb:.1f} MB", " | ".join(f"ks{k} w{w}: {u:.1f}us {mb / u * 1e-3 * 1e3:.0f}GB/s" for u, k, w in (res if "--all" in sys.argv else res[:6])), flush=True)
