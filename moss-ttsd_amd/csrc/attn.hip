@@ -13,7 +13,6 @@
 // HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.
 #include "common.h"
 
-#define ATT_PB 8   // pages per pass-B block (4 waves x 2 pages)
 
 // grid = (ceil(pages/4), nkv, R); block 256 = 4 waves, one page (64 tokens) per wave,
 // one token per lane: K page is [d/8][token][8] so lane t's 16 loads are 16 B each
@@ -186,12 +185,13 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
 // grid = (R, nq), block 128.  The chunk partials are loaded 8 at a time (independent loads; a loop that adds as it
 // loads would pay one memory round trip per chunk) and summed in chunk order.
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ opart, const RowMeta* __restrict__ meta,
-                                                           uint16_t* __restrict__ out_packed, int nchunks_max, int nq) {
+                                                           uint16_t* __restrict__ out_packed, int nchunks_max, int nq,
+                                                           int pages_per_chunk) {
     const int r = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
     const RowMeta m = meta[r];
     float s = 0.f;
     const int npages = m.seq >= 0 ? (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE : 0;
-    const int nch = (npages + ATT_PB - 1) / ATT_PB;
+    const int nch = (npages + pages_per_chunk - 1) / pages_per_chunk;
     const float* p = opart + ((size_t)r * nq + h) * nchunks_max * MTTS_HD + d;
     for (int c0 = 0; c0 < nch; c0 += 8) {
         float t[8];
@@ -204,12 +204,232 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
     out_packed[xpack_off(r, h * MTTS_HD + d, nq * MTTS_HD)] = f2bf(s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Prefill attention: the 32 rows of an activation tile are consecutive positions of ONE dialogue (the host
+// pads every dialogue's prompt to whole tiles), so a tile shares its K/V pages: one block streams a page once
+// for 32 query rows instead of once per row, with the products on the matrix cores.  Same rounding points,
+// same scratch (scores, per-page statistics, chunk partials) and the same combine kernel as the decode path.
+//   v_mfma_f32_32x32x16_bf16: A lane l = (row l&31, k 8*(l>>5)..+8), B lane l = (col l&31, k 8*(l>>5)..+8),
+//   D lane l = col l&31, rows (i&3) + 8*(i>>2) + 4*(l>>5) for i = 0..15.
+// ---------------------------------------------------------------------------------------------------
+
+// scores: D[token][row] = K page (A: tokens x d) . Q^T (B: d x rows).  grid = (ceil(pages/4), nkv, tiles),
+// block 256 = 4 waves, one page per wave.  The K page layout [d/8][token][8] is the A operand as stored.
+template <int G>
+__global__ __launch_bounds__(256) void attn_prefill_scores_kernel(
+    const uint16_t* __restrict__ qbuf, const u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
+    const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
+    int total_pages, int nq, int nkv, float scale) {
+    const int tile = blockIdx.z, kvh = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = tile * MTTS_MAXR + (lane & 31);
+    const RowMeta m0 = meta[tile * MTTS_MAXR];          // a tile with any live row has its first row live
+    if (m0.seq < 0) return;
+    const RowMeta mr = meta[row];
+    const int pos = mr.seq >= 0 ? mr.pos : -1;           // idle rows see no token
+    int maxpos = pos;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) maxpos = max(maxpos, __shfl_xor(maxpos, o, 64));
+    const int npages = (maxpos + 1 + MTTS_PAGE - 1) / MTTS_PAGE;
+    const int pg = blockIdx.x * 4 + wave;
+    if (pg >= npages) return;
+    const int page = page_table[(size_t)m0.seq * max_pages + pg];
+    const u32x4_t* kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8);
+    // A fragments: token half th (32 tokens), d step ks (16 dims): 16-byte group (2*ks + (lane>>5)) of token th*32 + (lane&31)
+    u32x4_t ka[2][8];
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) ka[th][ks] = kp[(2 * ks + (lane >> 5)) * 64 + th * 32 + (lane & 31)];
+    const int Lmax = max_pages * MTTS_PAGE;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const int h = kvh * G + g;
+        const u32x4_t* qp = (const u32x4_t*)(qbuf + ((size_t)row * nq + h) * MTTS_HD);
+        u32x4_t qb[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qb[ks] = qp[2 * ks + (lane >> 5)];
+        float mx = -INFINITY;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[th][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                acc[th] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&ka[th][ks], *(bf16x8_t*)&qb[ks], acc[th], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int tok = pg * MTTS_PAGE + th * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const float sc = rbf(rbf(acc[th][i]) * scale);
+                const bool valid = tok <= pos;
+                if (valid) scores[((size_t)row * nq + h) * Lmax + tok] = f2bf(sc);
+                acc[th][i] = valid ? sc : -INFINITY;
+                mx = fmaxf(mx, acc[th][i]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // lanes l and l^32 hold the two halves of a row's tokens
+        float sm = 0.f;
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm += (acc[th][i] > -INFINITY) ? expf(acc[th][i] - mx) : 0.f;
+        sm += __shfl_xor(sm, 32, 64);
+        if (lane < 32 && mr.seq >= 0) {
+            float* st = stats + (((size_t)row * nq + h) * max_pages + pg) * 2;
+            st[0] = mx;
+            st[1] = sm;
+        }
+    }
+}
+
+// P.V: D[d][row] = V^T (A: d x tokens) . P^T (B: tokens x rows), probabilities rounded to bf16 first.
+// grid = (ceil(pages/(4*ATT_PF)), nkv, tiles), block 256: each wave owns ATT_PF pages and all 128 head dims and
+// writes its own chunk partial (chunks of ATT_PF pages for prefill rows), so there is no cross-wave reduction.
+// The V page layout [token pair][d][2] gives the A operand as four dwords per lane (8 consecutive tokens of one d).
+template <int G>
+__global__ __launch_bounds__(256) void attn_prefill_pv_kernel(
+    const uint16_t* __restrict__ scores, const float* __restrict__ stats, const uint32_t* __restrict__ vcache,
+    const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
+    int max_pages, int total_pages, int nchunks_pf, int nq, int nkv) {
+    constexpr int GP = G > 2 ? 2 : G;                    // heads per sweep over the pages (accumulator registers)
+    const int tile = blockIdx.z, kvh = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int row = tile * MTTS_MAXR + (lane & 31);
+    const RowMeta m0 = meta[tile * MTTS_MAXR];
+    if (m0.seq < 0) return;
+    const RowMeta mr = meta[row];
+    const int pos = mr.seq >= 0 ? mr.pos : -1;
+    int maxpos = pos;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) maxpos = max(maxpos, __shfl_xor(maxpos, o, 64));
+    const int npages = (maxpos + 1 + MTTS_PAGE - 1) / MTTS_PAGE;
+    if (chunk * ATT_PF >= npages) return;
+    const int rpages = (pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE;   // this row's own pages
+    const int Lmax = max_pages * MTTS_PAGE;
+    const int pg_end = min(npages, (chunk + 1) * ATT_PF);
+#pragma unroll 1
+    for (int g0 = 0; g0 < G; g0 += GP) {
+        // row-wide softmax statistics: the two lanes of a row take alternate pages, four loads in flight
+        float M[GP], S[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            const float* st = stats + ((size_t)row * nq + kvh * G + g0 + g) * max_pages * 2;
+            float mx = -INFINITY;
+            for (int p = half; p < rpages; p += 8) {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = st[2 * min(p + 2 * j, rpages - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, t[j]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sm = 0.f;
+            for (int p = half; p < rpages; p += 8) {
+                float2 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = *(const float2*)(st + 2 * min(p + 2 * j, rpages - 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (p + 2 * j < rpages) sm += t[j].y * expf(t[j].x - mx);
+            }
+            sm += __shfl_xor(sm, 32, 64);
+            M[g] = mx;
+            S[g] = sm;
+        }
+        f32x16_t acc[GP][4];
+#pragma unroll
+        for (int g = 0; g < GP; ++g)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[g][db][i] = 0.f;
+#pragma unroll 1
+        for (int pg = chunk * ATT_PF; pg < pg_end; ++pg) {
+            const int page = page_table[(size_t)m0.seq * max_pages + pg];
+            const uint32_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 2) + (lane & 31);
+            // the page's score words for this lane's rows/tokens go out first, then V
+            u32x4_t sv[4][GP];
+#pragma unroll
+            for (int ts = 0; ts < 4; ++ts) {
+                const int tok0 = pg * MTTS_PAGE + ts * 16 + 8 * half;
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    sv[ts][g] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (tok0 <= pos) sv[ts][g] = *(const u32x4_t*)(scores + ((size_t)row * nq + kvh * G + g0 + g) * Lmax + tok0);
+                }
+            }
+#pragma unroll
+            for (int ts = 0; ts < 4; ++ts) {                 // 16 tokens per MFMA
+                const int t0 = ts * 16 + 8 * half;           // this lane's 8 tokens inside the page
+                u32x4_t va[4];
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const uint32_t* q = vp + db * 32 + (size_t)(t0 / 2) * MTTS_HD;
+                    va[db].x = q[0];
+                    va[db].y = q[MTTS_HD];
+                    va[db].z = q[2 * MTTS_HD];
+                    va[db].w = q[3 * MTTS_HD];
+                }
+                const int tok0 = pg * MTTS_PAGE + t0;
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    const uint32_t sw[4] = {sv[ts][g].x, sv[ts][g].y, sv[ts][g].z, sv[ts][g].w};
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float p0 = (tok0 + 2 * j <= pos) ? expf(bflo(sw[j]) - M[g]) / S[g] : 0.f;
+                        const float p1 = (tok0 + 2 * j + 1 <= pos) ? expf(bfhi(sw[j]) - M[g]) / S[g] : 0.f;
+                        pw[j] = pack2(p0, p1);
+                    }
+                    u32x4_t pb = {pw[0], pw[1], pw[2], pw[3]};
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+                        acc[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&va[db], *(bf16x8_t*)&pb, acc[g][db], 0, 0, 0);
+                }
+            }
+        }
+        if (mr.seq >= 0) {
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                float* o = opart + (((size_t)row * nq + kvh * G + g0 + g) * nchunks_pf + chunk) * MTTS_HD + 4 * half;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v4 = make_float4(acc[g][db][4 * q], acc[g][db][4 * q + 1], acc[g][db][4 * q + 2], acc[g][db][4 * q + 3]);
+                        *(float4*)(o + db * 32 + 8 * q) = v4;
+                    }
+            }
+        }
+    }
+}
+
 template <int G>
 static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                           int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                           const int32_t* done, int phase, hipStream_t st) {
     (void)done;   // rows that are not running carry seq < 0 in their RowMeta
+    if (phase == 11) {   // prefill tiles (32 consecutive positions of one dialogue per tile)
+        dim3 ga((pages_bound + 3) / 4, nkv, R / MTTS_MAXR);
+        hipLaunchKernelGGL((attn_prefill_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
+                           page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale);
+        return;
+    }
+    const int nchunks_pf = (max_pages + ATT_PF - 1) / ATT_PF;      // prefill rows: chunks of ATT_PF pages
+    if (phase == 12) {
+        dim3 gb((pages_bound + 4 * ATT_PF - 1) / (4 * ATT_PF), nkv, R / MTTS_MAXR);
+        hipLaunchKernelGGL((attn_prefill_pv_kernel<G>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+                           (const uint32_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_pf, nq, nkv);
+        return;
+    }
+    if (phase == 13) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
+                           (uint16_t*)out_packed, nchunks_pf, nq, ATT_PF);
+        return;
+    }
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
         hipLaunchKernelGGL((attn_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
@@ -222,7 +442,7 @@ static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcac
     }
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
-                           (uint16_t*)out_packed, nchunks_max, nq);
+                           (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
 }
 
 int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,

@@ -15,6 +15,8 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 #define MTTS_RCAP 128         // rows (sequences or prefill tokens) per forward pass: up to 4 tiles share one weight stream
 #define MTTS_PAGE 64          // tokens per KV page
 #define MTTS_HD 128           // head_dim the kernels are written for
+#define ATT_PB 8              // KV pages per pass-B chunk, decode rows (4 waves x 2 pages)
+#define ATT_PF 2              // KV pages per pass-B chunk, prefill tiles (one wave)
 
 // bf16 bit pattern <-> fp32.  Round-to-nearest-even, NaN stays NaN, inf stays inf.
 __device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }

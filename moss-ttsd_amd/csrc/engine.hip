@@ -64,7 +64,6 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
 
 void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
                          int cap, hipStream_t st);
-#define ATT_PB 8
 
 // ---- errors -------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -147,6 +146,7 @@ struct MttsEngine {
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
+    int pf_mfma_pages = 16;             // prompts of this many KV pages or more prefill through the tile-sharing MFMA attention
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_N];
@@ -209,6 +209,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->cfg = *c;
     e->device = device;
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
+    if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
     e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
     e->V0 = c->vocab_size; e->Vs = c->speech_vocab_size;
@@ -266,7 +267,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
     TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_RCAP * e->nq * e->max_pages * MTTS_PAGE));
     TRY(dalloc(&e->stats, (size_t)MTTS_RCAP * e->nq * e->max_pages * 2));
-    TRY(dalloc(&e->opart, (size_t)MTTS_RCAP * e->nq * e->nchunks_max * MTTS_HD));
+    TRY(dalloc(&e->opart, (size_t)MTTS_RCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
     // state
     TRY(dalloc(&e->d_seqs, MTTS_RCAP));
     TRY(dalloc(&e->d_meta, MTTS_RCAP));
@@ -437,11 +438,15 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
                         kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
+        // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
+        // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
+        const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
         for (int phase = 1; phase <= 3; ++phase) {
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
-                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale, done, phase, st))
+                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale, done,
+                            ph0 + phase, st))
                 return fail(MTTS_EINVAL, "attention group size not built");
             if (phase < 3) prof_end(e, st, ev);
         }
@@ -525,14 +530,15 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         return fail(MTTS_EINVAL, "rope table has %d rows, need %d", e->rope_rows, e->max_real + max_steps);
     // generation buffers
     TRY(ensure_gen_storage(e, max_steps));
-    // flattened prefill rows
+    // flattened prefill rows; every dialogue starts on a 32-row tile boundary so that a tile holds consecutive
+    // positions of one dialogue (the prefill attention kernels share K/V pages across a tile); filler rows are idle
     size_t Mtot = 0;
-    for (int b = 0; b < B; ++b) Mtot += e->n_real[b];
+    for (int b = 0; b < B; ++b) Mtot += (size_t)round_up(e->n_real[b], MTTS_MAXR);
     size_t Mpad = (Mtot + MTTS_RCAP - 1) / MTTS_RCAP * MTTS_RCAP;
     std::vector<int32_t> toks(Mpad * 8, 0);
     std::vector<RowMeta> metas(Mpad, RowMeta{-1, 0, 0, 0});
     size_t r = 0;
-    for (int b = 0; b < B; ++b)
+    for (int b = 0; b < B; r = (r + MTTS_MAXR - 1) / MTTS_MAXR * MTTS_MAXR, ++b)
         for (int i = 0; i < e->n_real[b]; ++i, ++r) {
             const int64_t* src = ids + ((size_t)b * T + pad[b] + i) * 8;
             for (int c = 0; c < 8; ++c) {

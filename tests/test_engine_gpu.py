@@ -266,6 +266,44 @@ def test_engine_long_run_crosses_kv_pages_vs_oracle(engines):
     assert np.array_equal(dec[~free], want[~free])
 
 
+def test_long_ragged_prefill_vs_oracle():
+    """Prompts of 300..640 tokens, ragged: the prefill attention shares K/V pages across 32-row tiles on the matrix
+    cores (several tiles per dialogue, 10 pages, 2 pass-B chunks, dialogue boundaries inside a pass).  The logits
+    after the prefill and the decisions of the following steps must match the oracle's row-by-row computation."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 41, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    eng = Engine(cfg, max_batch=4, max_seq_len=1024)
+    eng.bind_state_dict(w)
+    ids, mask = synth.synth_prompts(cfg, 42, 3, 640, 0.4, True)
+    assert mask.sum(axis=1).min() >= 300 and mask.sum(axis=1).max() > 512      # > 8 pages: two pass-B chunks
+    T = ids.shape[1]
+    max_length = T + 12
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    gold = orc.generate(ids, mask, max_length)
+    margins = np.stack(orc.last_margins)
+    _, _, logs = orc.generate(ids, mask, max_length, forced=gold, return_logits=True, max_steps=2)
+    eng.begin(ids, mask, max_length)
+    l0, l17 = eng.read_logits()
+    exact = total = 0
+    for c in range(8):
+        got = l0 if c == 0 else l17[c - 1]
+        ref = logs[0][c]
+        fin = np.isfinite(ref)
+        tol = (2.0 ** -6) * np.abs(np.where(fin, ref, 0)).max(axis=-1, keepdims=True)
+        assert (np.abs(np.where(fin, got - np.where(fin, ref, 0), 0)) <= tol).all(), c
+        exact += int((got[fin] == ref[fin]).sum())
+        total += int(fin.sum())
+    assert exact >= 0.3 * total, (exact, total)
+    out, dec = eng.generate(ids, mask, max_length, forced=gold)
+    want = gold[:, T - 7:].transpose(1, 0, 2)
+    assert dec.shape == want.shape
+    safe = margins >= MARGIN_OK
+    bad = np.argwhere(safe & (dec != want))
+    assert len(bad) == 0, bad[:10]
+    eng.close()
+
+
 def _rand_weights_on_gpu(cfg, seed):
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
