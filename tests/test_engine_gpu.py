@@ -266,11 +266,14 @@ def test_engine_long_run_crosses_kv_pages_vs_oracle(engines):
     assert np.array_equal(dec[~free], want[~free])
 
 
-def test_long_ragged_prefill_vs_oracle():
-    """Prompts of 300..640 tokens, ragged: the prefill attention shares K/V pages across 32-row tiles on the matrix
-    cores (several tiles per dialogue, 10 pages, 2 pass-B chunks, dialogue boundaries inside a pass).  The logits
-    after the prefill and the decisions of the following steps must match the oracle's row-by-row computation."""
+@pytest.mark.parametrize("mfma_from_pages", ["0", "1000"])
+def test_long_ragged_prefill_vs_oracle(monkeypatch, mfma_from_pages):
+    """Prompts of 350..517 tokens, ragged, through both prefill attention paths: "0" = every prompt takes the
+    tile-sharing matrix-core kernels (several 32-row tiles per dialogue, 9 pages, 5 pass-B chunks, dialogue
+    boundaries inside a pass; the engine's default sends prompts of >= 16 pages there), "1000" = row-by-row kernels.
+    The logits after the prefill and the decisions of the following steps must match the oracle."""
     from mtts.engine import Engine
+    monkeypatch.setenv("MTTS_PREFILL_MFMA_PAGES", mfma_from_pages)
     cfg = synth.tiny()
     w = synth.synth_weights(cfg, 41, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
     eng = Engine(cfg, max_batch=4, max_seq_len=1024)
