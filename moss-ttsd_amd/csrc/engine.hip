@@ -26,6 +26,9 @@ GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit);
 GemmPlan mtts_plan_gemm_forced(int Npad, int K, int ksplit, int waves);
 void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                  float* partial, uint16_t* out, hipStream_t st);
+int mtts_tile_ksplit(int Npad, int K, int R);
+void launch_gemm_tile(int epi, int R, int ksplit, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                      float* partial, uint16_t* out, hipStream_t st);
 void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st);
 void launch_pack_rows(const void* src, void* dst, int R, int K, int tiles, hipStream_t st);
 void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st);
@@ -146,7 +149,7 @@ struct MttsEngine {
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
-    int pf_mfma_pages = 16;             // prompts of this many KV pages or more prefill through the tile-sharing MFMA attention
+    int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_N];
@@ -242,16 +245,16 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->p_d = mtts_plan_gemm(round_up(H, 32), I, 0);
     e->p_h0 = mtts_plan_gemm(e->V0_pad, H, 1);
     e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
-    size_t pmax = std::max({(size_t)e->p_qkv.ksplit * e->qkv_rows, (size_t)e->p_o.ksplit * round_up(H, 32),
-                            (size_t)e->p_d.ksplit * round_up(H, 32)});
-    TRY(dalloc(&e->partial, pmax * MTTS_RCAP));
-    TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_RCAP * H));
-    TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_RCAP * H));
+    // activations hold a whole prefill pass (MTTS_PFCAP rows); split-K slabs: up to 8 of [MTTS_PFCAP][Npad] fp32
+    size_t pmax = (size_t)8 * std::max(e->qkv_rows, round_up(H, 32));
+    TRY(dalloc(&e->partial, pmax * MTTS_PFCAP));
+    TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_PFCAP * H));
+    TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_PFCAP * H));
     TRY(dalloc((uint16_t**)&e->xh, (size_t)MTTS_RCAP * H));
     TRY(dalloc((uint16_t**)&e->hlast, (size_t)MTTS_RCAP * H));
-    TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_RCAP * e->nq * MTTS_HD));
-    TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_RCAP * I));
-    TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_RCAP * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_PFCAP * e->nq * MTTS_HD));
+    TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_PFCAP * I));
+    TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_PFCAP * e->nq * MTTS_HD));
     TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
     TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
     TRY(dalloc((uint16_t**)&e->join_logits0, (size_t)MTTS_MAXR * e->V0));
@@ -265,9 +268,9 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
     TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
-    TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_RCAP * e->nq * e->max_pages * MTTS_PAGE));
-    TRY(dalloc(&e->stats, (size_t)MTTS_RCAP * e->nq * e->max_pages * 2));
-    TRY(dalloc(&e->opart, (size_t)MTTS_RCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
+    TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_PFCAP * e->nq * e->max_pages * MTTS_PAGE));
+    TRY(dalloc(&e->stats, (size_t)MTTS_PFCAP * e->nq * e->max_pages * 2));
+    TRY(dalloc(&e->opart, (size_t)MTTS_PFCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
     // state
     TRY(dalloc(&e->d_seqs, MTTS_RCAP));
     TRY(dalloc(&e->d_meta, MTTS_RCAP));
@@ -430,13 +433,20 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
     const int Hp = round_up(H, 32);
     const int mb = (R + 31) / 32;                    // activation row tiles sharing each weight stream
+    // prefill passes always take the tiled GEMM with a split-K that depends on the shape only: a prompt's
+    // hidden states then do not depend on how many rows (other dialogues) share its pass
+    const bool tiled = heads != 1;
     launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, done, st);
     for (int n = 0; n < e->L; ++n) {
         Layer& l = e->layers[n];
         uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
         uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
-        launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
-        launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
+        const int ks_qkv = tiled ? mtts_tile_ksplit(e->qkv_rows, H, MTTS_PFCAP) : e->p_qkv.ksplit;
+        const int ks_o = tiled ? mtts_tile_ksplit(Hp, nq * MTTS_HD, MTTS_PFCAP) : e->p_o.ksplit;
+        const int ks_d = tiled ? mtts_tile_ksplit(Hp, I, MTTS_PFCAP) : e->p_d.ksplit;
+        if (tiled) launch_gemm_tile(EPI_PARTIAL, R, ks_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
+        else launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
+        launch_qkv_post(e->partial, ks_qkv, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
                         kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
         // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
         // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
@@ -454,13 +464,19 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
             e->prof_bytes[PROF_SCORES] += kv_tokens_hint * nkv * MTTS_HD * 2;
             e->prof_bytes[PROF_PV] += kv_tokens_hint * nkv * MTTS_HD * 2;
         }
-        launch_gemm(EPI_PARTIAL, mb, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
-        launch_resid_norm(e->partial, e->p_o.ksplit, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, done, st);
-        launch_gemm(EPI_SILU, mb, e->p_gu, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
-        launch_gemm(EPI_PARTIAL, mb, e->p_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
+        if (tiled) launch_gemm_tile(EPI_PARTIAL, R, ks_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
+        else launch_gemm(EPI_PARTIAL, mb, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
+        launch_resid_norm(e->partial, ks_o, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, done, st);
+        if (tiled) {
+            launch_gemm_tile(EPI_SILU, R, 1, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
+            launch_gemm_tile(EPI_PARTIAL, R, ks_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
+        } else {
+            launch_gemm(EPI_SILU, mb, e->p_gu, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
+            launch_gemm(EPI_PARTIAL, mb, e->p_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
+        }
         const bool lastl = (n == e->L - 1);
         const void* nw = lastl ? e->final_norm : e->layers[n + 1].ln_in;
-        launch_resid_norm(e->partial, e->p_d.ksplit, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps,
+        launch_resid_norm(e->partial, ks_d, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps,
                           done, st);
     }
     if (heads) {
@@ -596,10 +612,10 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     }
     // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
     const int pages_bound = (e->max_real + MTTS_PAGE - 1) / MTTS_PAGE;
-    for (size_t off = 0; off < Mpad; off += MTTS_RCAP) {
-        bool lastc = off + MTTS_RCAP >= Mpad;
-        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_RCAP, pages_bound, lastc ? 2 : 0, nullptr,
-                         st, 0));
+    for (size_t off = 0; off < Mpad; off += MTTS_PFCAP) {
+        const int rows = (int)std::min<size_t>(MTTS_PFCAP, Mpad - off);     // multiple of MTTS_RCAP
+        const bool lastc = off + rows >= Mpad;
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, rows, pages_bound, lastc ? 2 : 0, nullptr, st, 0));
     }
     e->began = true;
     return MTTS_OK;
@@ -860,8 +876,9 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     HIPCHK(hipMemcpy(e->d_bitmaps + (size_t)slot * 8 * e->bm_words, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_tf + (size_t)slot * 7 * 8, tf.data(), tf.size() * 4, hipMemcpyHostToDevice));
     const int pages_bound = (n + MTTS_PAGE - 1) / MTTS_PAGE;
-    for (size_t off = 0; off < Mpad; off += MTTS_RCAP)
-        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, MTTS_RCAP, pages_bound, 0, nullptr, st, 0));
+    for (size_t off = 0; off < Mpad; off += MTTS_PFCAP)
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, (int)std::min<size_t>(MTTS_PFCAP, Mpad - off),
+                         pages_bound, 0, nullptr, st, 0));
     // logits of the dialogue's last prompt token only: heads on a one-row activation tile, copied into its slot
     // (the other slots' logits belong to dialogues that are mid-flight)
     HIPCHK(hipMemsetAsync(e->xh, 0, (size_t)MTTS_MAXR * e->H * 2, st));
@@ -951,20 +968,24 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 
 // ---- per-kernel entry points --------------------------------------------------------
 int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream) {
-    if (!w || !x || !y || M < 1 || M > MTTS_RCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=128, K%%16==0");
+    if (!w || !x || !y || M < 1 || M > MTTS_PFCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=512, K%%16==0");
     hipStream_t st = S(stream);
     int Npad = round_up(N, 32);
     void *wp = nullptr, *xp = nullptr;
     float* part = nullptr;
     GemmPlan p = mtts_plan_gemm(Npad, K, ksplit);
     TRY(dalloc((uint16_t**)&wp, (size_t)Npad * K));
-    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_RCAP * K));
-    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_RCAP * Npad));
+    // M <= 128: skinny kernel (decode); above: tiled kernel (prefill), ksplit as given or its own choice
+    const bool tiled = M > MTTS_RCAP;
+    const int ks = tiled ? (ksplit > 0 ? ksplit : mtts_tile_ksplit(Npad, K, M)) : p.ksplit;
+    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_PFCAP * K));
+    TRY(dalloc(&part, (size_t)ks * MTTS_PFCAP * Npad));
     launch_pack_weight(w, wp, N, K, Npad, 1, 0, st);
     const int tiles = (M + 31) / 32;
     launch_pack_rows(x, xp, M, K, tiles == 3 ? 4 : tiles, st);
-    launch_gemm(EPI_PARTIAL, tiles, p, wp, xp, K, Npad, Npad, part, nullptr, st);
-    launch_reduce_partial_bf16(part, y, p.ksplit, Npad, N, M, st);
+    if (tiled) launch_gemm_tile(EPI_PARTIAL, M, ks, wp, xp, K, Npad, Npad, part, nullptr, st);
+    else launch_gemm(EPI_PARTIAL, tiles, p, wp, xp, K, Npad, Npad, part, nullptr, st);
+    launch_reduce_partial_bf16(part, y, ks, Npad, N, M, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     hipFree(wp); hipFree(xp); hipFree(part);
@@ -1085,7 +1106,7 @@ extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t 
     TRY(dalloc(&x, (size_t)MTTS_RCAP * K, false));
     HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_RCAP * K * 2));
     TRY(dalloc(&out, (size_t)MTTS_RCAP * N));
-    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_RCAP * N));
+    TRY(dalloc(&part, (size_t)p.ksplit * MTTS_PFCAP * N));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < copies; ++i) launch_gemm(epi, 1, p, w[i], x, K, N, N, part, out, nullptr);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
             const int n0 = nt * 32 + nl;
             if (EPI == EPI_PARTIAL) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                *(float4*)(partial + ((size_t)ks * MTTS_RCAP + row) * Npad + n0) = o;
+                *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + row) * Npad + n0) = o;
             } else if (EPI == EPI_BF16) {
                 // row-major [rows][n_valid] bf16 (logits): rows are not 8-byte aligned when n_valid is odd
                 uint16_t* o = out + (size_t)row * n_valid + n0;
@@ -96,6 +96,96 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
                     float a = rbf(g / (1.0f + expf(-g)));
                     int idx = (n0 >> 1) + j;
                     out[xpack_off(row, idx, Npad >> 1)] = f2bf(a * u);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prefill GEMM: Y[R rows, N] = X[R, K] * W[N, K]^T for R up to MTTS_PFCAP rows per pass (compute-bound side of
+// the path: 2*R*N*K flops on the matrix cores against one read of W).  Same fragment layouts as the skinny
+// kernel, so W and X fragments are contiguous KiB loads straight into MFMA operands (no LDS): a block of
+// 4 waves (2 x 2) owns 128 rows x 128 columns, a wave 64 x 64 = 2 x 2 accumulators; the two waves that share a
+// W (or X) fragment hit the same lines in L1.  Same epilogues and rounding points as the skinny kernel.
+// grid = (ceil(N/128), ceil(R/128), ksplit).
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(
+    const u32x4_t* __restrict__ Wp, const u32x4_t* __restrict__ Xp, int KT, int kt_per_split, int ntiles, int rtiles,
+    float* __restrict__ partial, uint16_t* __restrict__ out, int Npad, int n_valid) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nt0 = blockIdx.x * 4 + (wave & 1) * 2;       // first of this wave's two 32-column tiles
+    const int rt0 = blockIdx.y * 4 + (wave >> 1) * 2;      // first of its two 32-row tiles
+    if (nt0 >= ntiles || rt0 >= rtiles) return;
+    const bool n1 = nt0 + 1 < ntiles, r1 = rt0 + 1 < rtiles;
+    const int ks = blockIdx.z;
+    const int kt0 = ks * kt_per_split, kt1 = min(kt0 + kt_per_split, KT);
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const size_t xtile = (size_t)KT * 64;
+    const u32x4_t* w0 = Wp + ((size_t)nt0 * KT + kt0) * 64 + lane;
+    const u32x4_t* w1 = Wp + ((size_t)(n1 ? nt0 + 1 : nt0) * KT + kt0) * 64 + lane;
+    const u32x4_t* x0 = Xp + (size_t)rt0 * xtile + (size_t)kt0 * 64 + lane;
+    const u32x4_t* x1 = Xp + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + (size_t)kt0 * 64 + lane;
+    constexpr int U = 4;
+    const int n = kt1 - kt0;
+    int i = 0;
+    for (; i + U <= n; i += U) {
+        u32x4_t a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a0[u] = w0[(size_t)(i + u) * 64];
+            a1[u] = w1[(size_t)(i + u) * 64];
+            b0[u] = x0[(size_t)(i + u) * 64];
+            b1[u] = x1[(size_t)(i + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a0[u], *(bf16x8_t*)&b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a0[u], *(bf16x8_t*)&b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a1[u], *(bf16x8_t*)&b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a1[u], *(bf16x8_t*)&b1[u], acc[1][1], 0, 0, 0);
+        }
+    }
+    for (; i < n; ++i) {
+        const u32x4_t a0 = w0[(size_t)i * 64], a1 = w1[(size_t)i * 64], b0 = x0[(size_t)i * 64], b1 = x1[(size_t)i * 64];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a0, *(bf16x8_t*)&b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a0, *(bf16x8_t*)&b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a1, *(bf16x8_t*)&b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a1, *(bf16x8_t*)&b1, acc[1][1], 0, 0, 0);
+    }
+    // D[n][row]: lane holds column row = lane&31 and n = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a && !n1) break;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b && !r1) break;
+            const int row = (rt0 + b) * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                const int n0 = (nt0 + a) * 32 + 8 * q + 4 * (lane >> 5);
+                if (EPI == EPI_PARTIAL) {
+                    *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + row) * Npad + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == EPI_BF16) {
+                    uint16_t* o = out + (size_t)row * n_valid + n0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float g = rbf(v[2 * j]), u = rbf(v[2 * j + 1]);
+                        float s = rbf(g / (1.0f + expf(-g)));
+                        out[xpack_off(row, (n0 >> 1) + j, Npad >> 1)] = f2bf(s * u);
+                    }
                 }
             }
         }
@@ -146,7 +236,7 @@ __global__ void reduce_partial_bf16_kernel(const float* __restrict__ partial, ui
     if (idx >= R * n_valid) return;
     int r = idx / n_valid, n = idx % n_valid;
     float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += partial[((size_t)k * MTTS_RCAP + r) * Npad + n];
+    for (int k = 0; k < ksplit; ++k) s += partial[((size_t)k * MTTS_PFCAP + r) * Npad + n];
     out[idx] = f2bf(s);
 }
 
@@ -208,6 +298,27 @@ void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void*
     if (epi == EPI_PARTIAL) launch_gemm_mb<EPI_PARTIAL>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
     else if (epi == EPI_BF16) launch_gemm_mb<EPI_BF16>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
     else launch_gemm_mb<EPI_SILU>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
+}
+
+
+// Tiled launch for R > 128 rows (prefill passes).  ksplit only where the grid would leave most CUs idle.
+int mtts_tile_ksplit(int Npad, int K, int R) {
+    int blocks = ((Npad + 127) / 128) * ((R + 127) / 128), ks = 1;
+    while (blocks * ks < 192 && ks < 8 && (K / 16) / (ks * 2) >= 16) ks *= 2;
+    return ks;
+}
+void launch_gemm_tile(int epi, int R, int ksplit, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
+                      float* partial, uint16_t* out, hipStream_t st) {
+    const int KT = K / 16, ntiles = Npad / 32, rtiles = (R + 31) / 32;
+    const int kps = (KT + ksplit - 1) / ksplit;
+    dim3 grid((ntiles + 3) / 4, (rtiles + 3) / 4, ksplit);
+#define MTTS_TILE_CASE(E)                                                                                     \
+    hipLaunchKernelGGL((gemm_tile_kernel<E>), grid, dim3(256), 0, st, (const u32x4_t*)Wp, (const u32x4_t*)Xp, \
+                       KT, kps, ntiles, rtiles, partial, out, Npad, n_valid)
+    if (epi == EPI_PARTIAL) MTTS_TILE_CASE(EPI_PARTIAL);
+    else if (epi == EPI_BF16) MTTS_TILE_CASE(EPI_BF16);
+    else MTTS_TILE_CASE(EPI_SILU);
+#undef MTTS_TILE_CASE
 }
 
 GemmPlan mtts_plan_gemm(int Npad, int K, int want_ksplit) { return plan_gemm(Npad, K, want_ksplit); }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
     const RowMeta* __restrict__ meta, int H, float eps) {
     __shared__ float sh[4];
     const int r = blockIdx.x;
-    const size_t kstride = (size_t)MTTS_RCAP * Npad;
+    const size_t kstride = (size_t)MTTS_PFCAP * Npad;
     // each thread owns 8 consecutive elements per 2048-wide chunk (16-byte loads/stores; the 8
     // elements are one 16-byte group of the X-fragment layout); values stay in registers.
     constexpr int MAXC = 4;                       // H <= 8192
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(
     const int32_t* __restrict__ page_table, int max_pages, int total_pages, int nq, int nkv, float eps) {
     const int r = blockIdx.x, h = blockIdx.y, l = threadIdx.x;
     const int col = h * MTTS_HD;
-    const size_t kstride = (size_t)MTTS_RCAP * Npad;
+    const size_t kstride = (size_t)MTTS_PFCAP * Npad;
     const float* p0 = partial + (size_t)r * Npad + col + l;
     // all loads go out before anything is waited for: the split-K slabs (fixed summation order), then the
     // row's position -> page / RoPE row.  Idle rows (seq < 0) run on clamped indices and store nothing.

@@ -25,7 +25,9 @@ def test_gemm_kernel_matches_fp32_reference():
     rng = np.random.default_rng(0)
     lib = capi.lib()
     for (M, N, K, ks) in [(32, 1024, 256, 0), (5, 4096, 2048, 0), (32, 2048, 6144, 4), (17, 1025, 512, 1), (32, 96, 64, 1),
-                          (100, 1024, 512, 0), (128, 2048, 2048, 2), (64, 4096, 256, 1)]:
+                          (100, 1024, 512, 0), (128, 2048, 2048, 2), (64, 4096, 256, 1),
+                          # > 128 rows: the tiled prefill kernel (128 x 128 blocks), ragged rows / columns, split-K
+                          (512, 2048, 2048, 0), (384, 4096, 512, 1), (200, 1025, 512, 2), (160, 96, 64, 1), (512, 256, 6144, 4)]:
         w = ao.round_bf16(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
         x = ao.round_bf16(rng.standard_normal((M, K)).astype(np.float32))
         wt, xt = _bf16_t(w), _bf16_t(x)
