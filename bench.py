@@ -240,6 +240,9 @@ def main():
     ids, mask = synth.synth_prompts(cfg, 77 + rank, B, T, audio_frac=0.5, ragged=False)
     layers = [dict(top_k=50, top_p=0.95, temperature=1.0, repetition_penalty=1.0)] * 8
     max_length = T + (L - n_real) + 8
+    H_, I_, nl_ = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    stack_params = nl_ * (H_ * (cfg["num_attention_heads"] + 2 * cfg["num_key_value_heads"]) * cfg["head_dim"]
+                          + cfg["num_attention_heads"] * cfg["head_dim"] * H_ + 3 * H_ * I_)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.begin(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=42 + rank)
@@ -329,6 +332,10 @@ def main():
             "step_hbm_roofline_frac": (step_bytes / (dt_max / K)) / 1e9 / HBM_PEAK_GBS,
             "ramp_frames_per_s": B * ramp / t_ramp if ramp else None,
             "prefill_s": t_prefill, "setup_s": time.perf_counter() - t_setup,
+            # prompt pass, compute-bound side: 2 * (decoder-stack parameters) * prompt tokens (the heads run on the last
+            # token of each dialogue only), against the dense bf16 MFMA peak
+            "prefill": {"tokens": int(B * n_real), "tokens_per_s": B * n_real / t_prefill,
+                        "tflops": 2.0 * stack_params * B * n_real / t_prefill / 1e12, "mfma_peak_tflops": 2500.0},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

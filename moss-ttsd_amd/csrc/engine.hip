@@ -1098,21 +1098,29 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
 extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,
                                      int32_t iters, float* avg_us) {
     if (N % 32 || K % 16 || copies < 1 || iters < 1 || !avg_us) return fail(MTTS_EINVAL, "gemm_bench: bad argument");
-    GemmPlan p = (ksplit > 0 && waves > 0) ? mtts_plan_gemm_forced(N, K, ksplit, waves) : mtts_plan_gemm(N, K, ksplit);
+    // waves < 0: the tiled prefill kernel on -waves rows (<= MTTS_PFCAP), split-K as given
+    const int tile_rows = waves < 0 ? -waves : 0;
+    if (tile_rows > MTTS_PFCAP) return fail(MTTS_EINVAL, "gemm_bench: at most 512 rows");
+    GemmPlan p = (ksplit > 0 && waves > 0) ? mtts_plan_gemm_forced(N, K, ksplit, waves) : mtts_plan_gemm(N, K, tile_rows ? std::max(ksplit, 1) : ksplit);
+    if (tile_rows) p.ksplit = std::max(ksplit, 1);
     std::vector<uint16_t*> w(copies, nullptr);
     for (auto& q : w) { TRY(dalloc(&q, (size_t)N * K, false)); HIPCHK(hipMemset(q, 0x3c, (size_t)N * K * 2)); }
     uint16_t *x = nullptr, *out = nullptr;
     float* part = nullptr;
-    TRY(dalloc(&x, (size_t)MTTS_RCAP * K, false));
-    HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_RCAP * K * 2));
-    TRY(dalloc(&out, (size_t)MTTS_RCAP * N));
+    TRY(dalloc(&x, (size_t)MTTS_PFCAP * K, false));
+    HIPCHK(hipMemset(x, 0x3c, (size_t)MTTS_PFCAP * K * 2));
+    TRY(dalloc(&out, (size_t)MTTS_PFCAP * N));
     TRY(dalloc(&part, (size_t)p.ksplit * MTTS_PFCAP * N));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < copies; ++i) launch_gemm(epi, 1, p, w[i], x, K, N, N, part, out, nullptr);
+    auto go = [&](int i) {
+        if (tile_rows) launch_gemm_tile(epi, tile_rows, p.ksplit, w[i % copies], x, K, N, N, part, out, nullptr);
+        else launch_gemm(epi, 1, p, w[i % copies], x, K, N, N, part, out, nullptr);
+    };
+    for (int i = 0; i < copies; ++i) go(i);
     HIPCHK(hipDeviceSynchronize());
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) launch_gemm(epi, 1, p, w[i % copies], x, K, N, N, part, out, nullptr);
+    for (int i = 0; i < iters; ++i) go(i);
     hipEventRecord(e1, nullptr);
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;

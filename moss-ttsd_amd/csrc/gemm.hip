@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
     const u32x4_t* w1 = Wp + ((size_t)(n1 ? nt0 + 1 : nt0) * KT + kt0) * 64 + lane;
     const u32x4_t* x0 = Xp + (size_t)rt0 * xtile + (size_t)kt0 * 64 + lane;
     const u32x4_t* x1 = Xp + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + (size_t)kt0 * 64 + lane;
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int n = kt1 - kt0;
     int i = 0;
     for (; i + U <= n; i += U) {
@@ -304,7 +304,7 @@ void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void*
 // Tiled launch for R > 128 rows (prefill passes).  ksplit only where the grid would leave most CUs idle.
 int mtts_tile_ksplit(int Npad, int K, int R) {
     int blocks = ((Npad + 127) / 128) * ((R + 127) / 128), ks = 1;
-    while (blocks * ks < 192 && ks < 8 && (K / 16) / (ks * 2) >= 16) ks *= 2;
+    while (blocks * ks < 512 && ks < 8 && (K / 16) / (ks * 2) >= 16) ks *= 2;
     return ks;
 }
 void launch_gemm_tile(int epi, int R, int ksplit, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
