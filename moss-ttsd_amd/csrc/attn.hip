@@ -17,12 +17,58 @@
 // grid = (ceil(pages/4), nkv, R); block 256 = 4 waves, one page (64 tokens) per wave,
 // one token per lane: K page is [d/8][token][8] so lane t's 16 loads are 16 B each
 // and every wave-instruction covers one contiguous KiB.
-template <int G>
+// Sum of the qkv GEMM's split-K slabs for head column `col` of row r: lane l gets d = l and d = l + 64 (all loads
+// in flight at once, fixed summation order), rounded to bf16 like the Linear's output.
+__device__ __forceinline__ void fuse_reduce(const QkvFuse& f, int r, int col, int lane, float& a, float& b) {
+    const size_t kstride = (size_t)MTTS_PFCAP * f.Npad;
+    const float* p0 = f.partial + (size_t)r * f.Npad + col + lane;
+    a = 0.f; b = 0.f;
+    for (int k0 = 0; k0 < f.ksplit; k0 += 8) {
+        float ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* pk = p0 + (size_t)min(k0 + j, f.ksplit - 1) * kstride;
+            ta[j] = pk[0];
+            tb[j] = pk[64];
+        }
+        if (k0 == 0) { a = ta[0]; b = tb[0]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < f.ksplit && k0 + j > 0) { a += ta[j]; b += tb[j]; }
+    }
+    a = rbf(a);
+    b = rbf(b);
+}
+
+// per-head RMSNorm + RoPE of one q or k head held as (a = x[l], b = x[l+64]) across a wave (qkv_post_kernel's math).
+// The norm weights and the RoPE row are loaded before the slabs are waited for (one memory round trip, not two).
+struct FuseVec { float w0, w1, c, s; };
+__device__ __forceinline__ FuseVec fuse_load_vec(const QkvFuse& f, const uint16_t* __restrict__ nw, int pos, int lane) {
+    FuseVec v;
+    v.w0 = bf2f(nw[lane]);
+    v.w1 = bf2f(nw[lane + 64]);
+    v.c = bf2f(f.rope_cos[(size_t)pos * 64 + lane]);
+    v.s = bf2f(f.rope_sin[(size_t)pos * 64 + lane]);
+    return v;
+}
+__device__ __forceinline__ void fuse_norm_rope(const QkvFuse& f, const FuseVec& v, float a, float b, float& o1, float& o2) {
+    const float ss = wave_sum(a * a + b * b);
+    const float inv = 1.0f / sqrtf(ss / (float)MTTS_HD + f.eps);
+    a = rbf(v.w0 * rbf(a * inv));
+    b = rbf(v.w1 * rbf(b * inv));
+    o1 = rbf(rbf(a * v.c) + rbf(-b * v.s));
+    o2 = rbf(rbf(b * v.c) + rbf(a * v.s));
+}
+
+// FUSED (decode rows): q comes from the qkv GEMM's slabs (reduce, RMSNorm, RoPE done here, one head per wave), and the
+// block whose pages hold position `pos` also produces the new K row, writes it to the cache and uses it from LDS.
+template <int G, bool FUSED>
 __global__ __launch_bounds__(256) void attn_scores_kernel(
-    const uint16_t* __restrict__ qbuf, const u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
+    const uint16_t* __restrict__ qbuf, u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
     const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
-    int total_pages, int nq, int nkv, float scale) {
+    int total_pages, int nq, int nkv, float scale, QkvFuse f) {
     __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
+    __shared__ __attribute__((aligned(16))) uint16_t knew[MTTS_HD];
     const int r = blockIdx.z, kvh = blockIdx.y;
     const RowMeta m = meta[r];
     if (m.seq < 0) return;
@@ -39,12 +85,40 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
     }
-    for (int i = threadIdx.x; i < G * MTTS_HD / 2; i += 256) {
-        int g = i / (MTTS_HD / 2), d2 = i % (MTTS_HD / 2);
-        qs[g][d2] = ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G + g) * (MTTS_HD / 2) + d2];
+    const int own_pg = m.pos >> 6;                    // page that receives this step's token
+    if (FUSED) {
+        const bool own = (own_pg >> 2) == (int)blockIdx.x;
+        for (int hh = wave; hh < G + (own ? 1 : 0); hh += 4) {
+            const bool isk = hh == G;
+            float a, b, o1, o2;
+            const FuseVec fv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
+            fuse_reduce(f, r, (isk ? nq + kvh : kvh * G + hh) * MTTS_HD, lane, a, b);
+            fuse_norm_rope(f, fv, a, b, o1, o2);
+            if (!isk) {
+                ((uint16_t*)qs[hh])[lane] = f2bf(o1);
+                ((uint16_t*)qs[hh])[lane + 64] = f2bf(o2);
+            } else {
+                knew[lane] = f2bf(o1);
+                knew[lane + 64] = f2bf(o2);
+                const int page = page_table[(size_t)m.seq * max_pages + own_pg];
+                uint16_t* base = (uint16_t*)kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD);
+                const int tok = m.pos & 63;        // element (tok, d) at ((d/8)*64 + tok)*8 + d%8
+                base[(((lane >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o1);
+                base[((((lane + 64) >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o2);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < G * MTTS_HD / 2; i += 256) {
+            int g = i / (MTTS_HD / 2), d2 = i % (MTTS_HD / 2);
+            qs[g][d2] = ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G + g) * (MTTS_HD / 2) + d2];
+        }
     }
     __syncthreads();
     if (pg >= npages) return;
+    if (FUSED && pg == own_pg && lane == (m.pos & 63)) {      // this lane's token is the new one: take its K from LDS
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kv[j] = *(const u32x4_t*)&knew[8 * j];
+    }
     float acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.f;
@@ -85,13 +159,16 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 // (v[2i][d], v[2i+1][d]) so that P.V is a v_dot2c_f32_bf16 against the packed (already bf16-rounded,
 // hence exact) probability pair: out[d] += p[2i]*v[2i][d] + p[2i+1]*v[2i+1][d].  Lane l covers
 // d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
-template <int G>
+// FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
+// writes it to the cache and patches it into the page it has just loaded.
+template <int G, bool FUSED>
 __global__ __launch_bounds__(256) void attn_pv_kernel(
-    const uint16_t* __restrict__ scores, const float* __restrict__ stats, const u32x4_t* __restrict__ vcache,
+    const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
-    int max_pages, int total_pages, int nchunks_max, int nq, int nkv) {
+    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f) {
     __shared__ float red[4][G][MTTS_HD];
     __shared__ uint16_t pbuf[4][G][MTTS_PAGE];
+    __shared__ __attribute__((aligned(16))) uint16_t vnew[MTTS_HD];
     const int r = blockIdx.z, kvh = blockIdx.y, chunk = blockIdx.x;
     const RowMeta m = meta[r];
     if (m.seq < 0) return;
@@ -109,6 +186,19 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
         const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
         for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+    }
+    const int own_pg = m.pos >> 6;
+    const bool own_wave = FUSED && own_pg >= pg && own_pg < pg + ATT_PB / 4;       // one wave per (row, kv head)
+    if (own_wave) {
+        float a, b;
+        fuse_reduce(f, r, (nq + nkv + kvh) * MTTS_HD, lane, a, b);
+        vnew[lane] = f2bf(a);
+        vnew[lane + 64] = f2bf(b);
+        const int page = page_table[(size_t)m.seq * max_pages + own_pg];
+        const int tok = m.pos & 63;          // element (tok, d) at ((tok>>1)*128 + d)*2 + (tok&1)
+        uint16_t* dst = (uint16_t*)vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD) + (size_t)(tok >> 1) * (MTTS_HD * 2) + (tok & 1);
+        dst[2 * lane] = f2bf(a);
+        dst[2 * (lane + 64)] = f2bf(b);
     }
     // row-wide softmax statistics from the per-page (max, sumexp) pairs
     float M[G], S[G];
@@ -137,6 +227,24 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
             const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 #pragma unroll
             for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+        }
+        if (own_wave && pg == own_pg) {
+            // the page was loaded before the new row reached the cache: patch the token's half of its pair
+            __builtin_amdgcn_wave_barrier();
+            const int tp = (m.pos & 63) >> 1;             // token pair inside the page
+            if (sub == (tp & 1)) {
+                const uint32_t w01 = ((const uint32_t*)vnew)[2 * dl], w23 = ((const uint32_t*)vnew)[2 * dl + 1];
+                const uint32_t nv[4] = {w01 & 0xffffu, w01 >> 16, w23 & 0xffffu, w23 >> 16};   // d = 4*dl .. 4*dl+3
+                const bool hi = m.pos & 1;
+#pragma unroll
+                for (int it = 0; it < 16; ++it)
+                    if (it == (tp >> 1)) {
+                        vv[it].x = hi ? (vv[it].x & 0xffffu) | (nv[0] << 16) : (vv[it].x & 0xffff0000u) | nv[0];
+                        vv[it].y = hi ? (vv[it].y & 0xffffu) | (nv[1] << 16) : (vv[it].y & 0xffff0000u) | nv[1];
+                        vv[it].z = hi ? (vv[it].z & 0xffffu) | (nv[2] << 16) : (vv[it].z & 0xffff0000u) | nv[2];
+                        vv[it].w = hi ? (vv[it].w & 0xffffu) | (nv[3] << 16) : (vv[it].w & 0xffff0000u) | nv[3];
+                    }
+            }
         }
         // lane t rounds the probability of token pg*64+t once (bf16, as the reference stores it);
         // the V loop reads pairs back from LDS (same wave: LDS ops are ordered).
@@ -407,11 +515,10 @@ __global__ __launch_bounds__(256) void attn_prefill_pv_kernel(
 }
 
 template <int G>
-static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                           int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                          const int32_t* done, int phase, hipStream_t st) {
-    (void)done;   // rows that are not running carry seq < 0 in their RowMeta
+                          const QkvFuse* fuse, int phase, hipStream_t st) {
     if (phase == 11) {   // prefill tiles (32 consecutive positions of one dialogue per tile)
         dim3 ga((pages_bound + 3) / 4, nkv, R / MTTS_MAXR);
         hipLaunchKernelGGL((attn_prefill_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
@@ -430,29 +537,40 @@ static void launch_attn_g(const void* qbuf, const void* kcache, const void* vcac
                            (uint16_t*)out_packed, nchunks_pf, nq, ATT_PF);
         return;
     }
+    const QkvFuse f = fuse ? *fuse : QkvFuse{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f};
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
-        hipLaunchKernelGGL((attn_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
-                           page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale);
+        if (fuse)
+            hipLaunchKernelGGL((attn_scores_kernel<G, true>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache,
+                               page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f);
+        else
+            hipLaunchKernelGGL((attn_scores_kernel<G, false>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache,
+                               page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f);
     }
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
-        hipLaunchKernelGGL((attn_pv_kernel<G>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
-                           (const u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv);
+        if (fuse)
+            hipLaunchKernelGGL((attn_pv_kernel<G, true>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
+        else
+            hipLaunchKernelGGL((attn_pv_kernel<G, false>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
     }
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
 }
 
-int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+// phase 1/2/3 = scores / P.V / combine for decode-style rows (one dialogue per row), 11/12/13 = the same for prefill
+// tiles.  `fuse` (decode rows only) moves the q/k/v epilogue into phases 1 and 2: no qkv_post launch before them.
+int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
-                int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale, const int32_t* done,
-                int phase, hipStream_t st) {
+                int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
+                const QkvFuse* fuse, int phase, hipStream_t st) {
     int G = nq / nkv;
 #define MTTS_ATT(GG)                                                                                              \
     launch_attn_g<GG>(qbuf, kcache, vcache, page_table, meta, scores, stats, opart, out_packed, R, pages_bound,   \
-                      max_pages, total_pages, nchunks_max, nq, nkv, scale, done, phase, st)
+                      max_pages, total_pages, nchunks_max, nq, nkv, scale, fuse, phase, st)
     if (G == 1) MTTS_ATT(1);
     else if (G == 2) MTTS_ATT(2);
     else if (G == 4) MTTS_ATT(4);

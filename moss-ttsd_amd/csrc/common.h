@@ -59,6 +59,15 @@ __host__ __device__ __forceinline__ size_t xpack_off(int r, int k, int K) {
     return (size_t)(r >> 5) * 32 * K + (((size_t)(k >> 4) * 64) + (r & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
 }
 
+// Decode rows: the q/k/v epilogue (split-K reduce, per-head RMSNorm, RoPE, cache write) runs inside the attention
+// kernels instead of a launch of its own; they need the qkv GEMM's slabs and the layer's small vectors.
+struct QkvFuse {
+    const float* partial;      // [ksplit][MTTS_PFCAP][Npad] fp32
+    int ksplit, Npad;
+    const uint16_t *qnorm_w, *knorm_w, *rope_cos, *rope_sin;
+    float eps;
+};
+
 // Per-row metadata of one forward pass (R <= 32 rows).
 struct RowMeta {
     int32_t seq;     // sequence slot (page-table row), -1 = inactive row

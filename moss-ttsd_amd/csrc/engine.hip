@@ -42,10 +42,10 @@ void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* 
                      const int32_t* done, hipStream_t st);
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st);
 void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st);
-int launch_attn(const void* qbuf, const void* kcache, const void* vcache, const int32_t* page_table,
+int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                const int32_t* done, int phase, hipStream_t st);
+                const QkvFuse* fuse, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
 struct LoopState { int32_t step, done, continuous, B, error, gen_cap, pad0, pad1; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
@@ -149,6 +149,7 @@ struct MttsEngine {
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
+    bool fuse_qkv = true;               // decode: q/k/v epilogue inside the attention kernels (MTTS_FUSE_QKV=0: own launch)
     int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
     bool prof = false;
@@ -212,6 +213,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->cfg = *c;
     e->device = device;
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
+    if (const char* g = getenv("MTTS_FUSE_QKV")) e->fuse_qkv = atoi(g) != 0;
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
     e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
@@ -446,8 +448,14 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         const int ks_d = tiled ? mtts_tile_ksplit(Hp, I, MTTS_PFCAP) : e->p_d.ksplit;
         if (tiled) launch_gemm_tile(EPI_PARTIAL, R, ks_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         else launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
-        launch_qkv_post(e->partial, ks_qkv, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
-                        kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
+        // decode rows (one dialogue each): the q/k/v epilogue runs inside the attention kernels; prefill passes
+        // need every K/V row of the pass in the cache before any of its attention runs, so they keep the launch
+        const bool fused = heads == 1 && e->fuse_qkv;
+        const QkvFuse fz{e->partial, ks_qkv, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
+                         (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
+        if (!fused)
+            launch_qkv_post(e->partial, ks_qkv, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
+                            kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
         // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
         // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
         const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
@@ -455,8 +463,8 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
-                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale, done,
-                            ph0 + phase, st))
+                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
+                            fused ? &fz : nullptr, ph0 + phase, st))
                 return fail(MTTS_EINVAL, "attention group size not built");
             if (phase < 3) prof_end(e, st, ev);
         }
@@ -1070,8 +1078,12 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
             const int layer = i % e->L;
             uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * layer;
             uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * layer;
+            // the product's decode launch: q/k/v epilogue fused (the slabs are whatever the last step left there)
+            const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)e->layers[layer].qn,
+                             (const uint16_t*)e->layers[layer].kn, (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin,
+                             e->cfg.rms_norm_eps};
             launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
-                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, nullptr, phase, nullptr);
+                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->fuse_qkv ? &fz : nullptr, phase, nullptr);
         }
     };
     run(e->L);                               // warm-up
