@@ -149,7 +149,7 @@ struct MttsEngine {
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
-    bool fuse_qkv = true;               // decode: q/k/v epilogue inside the attention kernels (MTTS_FUSE_QKV=0: own launch)
+    int fuse_qkv_max = 1024;            // decode: q/k/v epilogue inside the attention kernels while rows x KV pages <= this
     int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
     bool prof = false;
@@ -213,7 +213,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->cfg = *c;
     e->device = device;
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
-    if (const char* g = getenv("MTTS_FUSE_QKV")) e->fuse_qkv = atoi(g) != 0;
+    if (const char* g = getenv("MTTS_FUSE_QKV_MAX")) e->fuse_qkv_max = atoi(g);
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
     e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
@@ -450,7 +450,9 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         else launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         // decode rows (one dialogue each): the q/k/v epilogue runs inside the attention kernels; prefill passes
         // need every K/V row of the pass in the cache before any of its attention runs, so they keep the launch
-        const bool fused = heads == 1 && e->fuse_qkv;
+        // (fused where it pays: every attention block repeats the q epilogue, which costs more than the saved launch
+        // once rows x pages is large -- measured break-even around 32 rows x 32 pages; the results are bit-identical)
+        const bool fused = heads == 1 && e->B * pages_bound <= e->fuse_qkv_max;
         const QkvFuse fz{e->partial, ks_qkv, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
                          (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
         if (!fused)
@@ -1083,7 +1085,7 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
                              (const uint16_t*)e->layers[layer].kn, (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin,
                              e->cfg.rms_norm_eps};
             launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
-                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->fuse_qkv ? &fz : nullptr, phase, nullptr);
+                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr, phase, nullptr);
         }
     };
     run(e->L);                               // warm-up

@@ -357,6 +357,29 @@ def test_full_size_batch_and_padding_invariance():
     eng.close()
 
 
+def test_decode_fused_and_unfused_qkv_epilogue_agree(monkeypatch):
+    """Decode steps run the q/k/v epilogue inside the attention kernels while rows x KV pages is small and as a
+    launch of its own above that (MTTS_FUSE_QKV_MAX): same arithmetic, so tokens must be identical, greedy and sampled,
+    across page boundaries (140 steps) and with a ragged batch."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 61, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = synth.synth_prompts(cfg, 62, 4, 40, 0.4, True)
+    max_length = ids.shape[1] + 140
+    layers = [dict(top_k=40, top_p=0.9, temperature=1.1, repetition_penalty=1.05)] * 8
+    outs = []
+    for limit in ("1000000", "0"):
+        monkeypatch.setenv("MTTS_FUSE_QKV_MAX", limit)
+        eng = Engine(cfg, max_batch=4, max_seq_len=256)
+        eng.bind_state_dict(w)
+        outs.append((eng.generate(ids, mask, max_length),
+                     eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=9)))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][0].shape[1] - (ids.shape[1] - 7) > 100       # the run did cross page boundaries
+
+
 def test_engine_multi_tile_batch_equals_single_tile(engines):
     """40 dialogues in ONE pass (two 32-row activation tiles share each weight stream) == the same
     dialogues served 32 + 8: per-row results do not depend on the tiling."""
