@@ -316,7 +316,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attention.json")))["kernels"]
             if B == 32 and L == 4096 and not args.layers:
-                traffic = pmc[dom + "<2>"]["hbm_bytes_per_launch"]
+                traffic = pmc[dom + "<2, false>"]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
         except Exception:
             traffic = None
         out = {
