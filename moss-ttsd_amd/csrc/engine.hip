@@ -1047,9 +1047,10 @@ extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
     if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipDeviceSynchronize());
-    const int limit = e->max_pages * MTTS_PAGE - MTTS_PAGE;
+    const int cap = std::min(e->max_pages * MTTS_PAGE, e->rope_rows);          // positions the pages and the RoPE table hold
+    const int limit = cap - MTTS_PAGE;
     if (kv_len < 1 || kv_len > limit) return fail(MTTS_EINVAL, "kv_len %d outside 1..%d", kv_len, limit);
-    e->max_steps = std::min(e->max_steps, e->steps_issued + e->max_pages * MTTS_PAGE - kv_len);   // stay inside the pages
+    e->max_steps = std::min(e->max_steps, e->steps_issued + cap - kv_len);   // stay inside the pages and the RoPE table
     std::vector<SeqState> ss(MTTS_RCAP);
     HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
     for (int b = 0; b < e->B; ++b) { ss[b].kv_len = kv_len; e->n_real[b] = kv_len - e->steps_issued; }

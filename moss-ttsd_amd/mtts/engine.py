@@ -125,12 +125,14 @@ class Engine:
         capi.check(self.lib.mtts_begin(self._h, ids.ctypes.data, m.ctypes.data, B, T, int(max_length),
                                        sampler_cfgs(layers, do_samples), C.c_uint64(seed), None))
 
-    def step(self, n=1):
-        capi.check(self.lib.mtts_step(self._h, int(n), None))
+    def step(self, n=1, stream=None):
+        """Issue n decode steps on `stream` (torch.cuda.Stream; default: the device's default stream)."""
+        capi.check(self.lib.mtts_step(self._h, int(n), C.c_void_p(stream.cuda_stream) if stream is not None else None))
 
-    def sync_state(self):
+    def sync_state(self, stream=None):
         s, d = C.c_int32(0), C.c_int32(0)
-        capi.check(self.lib.mtts_sync_state(self._h, C.byref(s), C.byref(d), None))
+        capi.check(self.lib.mtts_sync_state(self._h, C.byref(s), C.byref(d),
+                                            C.c_void_p(stream.cuda_stream) if stream is not None else None))
         return s.value, bool(d.value)
 
     def read_generated(self, capacity_steps):
