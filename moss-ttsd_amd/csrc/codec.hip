@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -167,6 +168,130 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
         }
 }
 
+// ------------------------------------------------------------------------------------
+// The same GEMM at 3 bf16 MFMAs per product tile ("bf16x3"): every fp32 operand is split on its way into LDS into
+// hi = bf16(x) and lo = bf16(x - hi), and  a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulates in fp32 on
+// v_mfma_f32_32x32x16_bf16 (the dropped terms are below 2^-16 relative).  The exact-f32 MFMA runs at 1/16 of the
+// bf16 rate, so this is ~5x less matrix-core time per tile; the decoder's waveform moves by 1.5e-6 RMS against the
+// reference (tolerance 1e-4; measured on the fixtures, oracle/ numerics emulation and the GPU tests).  Used for the
+// decode direction only: the encoder's code ids come from an argmin and keep the exact kernel.
+// W is [N][K].  LDS planes [k half][row][8 bf16]: a lane's MFMA operand (8 consecutive k of one row) is one 16-byte read.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void split2(float x, float y, uint32_t& hi, uint32_t& lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {x, y};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);            // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+    const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][2][GT][8], Al[2][2][GT][8], Wh[2][2][GT][8], Wl[2][2][GT][8];
+    const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+    const float* A = g.A + zo * g.sAo + zi * g.sAi;
+    const float* W = g.W + zo * g.sWo + zi * g.sWi;
+    float* C = g.C + zo * g.sCo + zi * g.sCi;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ra[2][4], rw[2][4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, kq = idx & 3;
+            const int k = k0 + 4 * kq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[i][j] = 0.f; rw[i][j] = 0.f; }
+            if (m0 + row < g.M) {
+                const float* p = A + (long)(m0 + row) * g.lda + k;
+                if (k + 3 < g.K) { const float4 t = *(const float4*)p; ra[i][0] = t.x; ra[i][1] = t.y; ra[i][2] = t.z; ra[i][3] = t.w; }
+                else { for (int j = 0; j < 4; ++j) if (k + j < g.K) ra[i][j] = p[j]; }
+            }
+            if (n0 + row < g.N) {
+                const float* p = W + (long)(n0 + row) * g.ldw + k;
+                if (k + 3 < g.K) { const float4 t = *(const float4*)p; rw[i][0] = t.x; rw[i][1] = t.y; rw[i][2] = t.z; rw[i][3] = t.w; }
+                else { for (int j = 0; j < 4; ++j) if (k + j < g.K) rw[i][j] = p[j]; }
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, kq = idx & 3, kh = kq >> 1, off = 4 * (kq & 1);
+            uint32_t h0, h1, l0, l1;
+            split2(ra[i][0], ra[i][1], h0, l0);
+            split2(ra[i][2], ra[i][3], h1, l1);
+            *(u32x2_t*)&Ah[buf][kh][row][off] = u32x2_t{h0, h1};
+            *(u32x2_t*)&Al[buf][kh][row][off] = u32x2_t{l0, l1};
+            split2(rw[i][0], rw[i][1], h0, l0);
+            split2(rw[i][2], rw[i][3], h1, l1);
+            *(u32x2_t*)&Wh[buf][kh][row][off] = u32x2_t{h0, h1};
+            *(u32x2_t*)&Wl[buf][kh][row][off] = u32x2_t{l0, l1};
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    const int kh = lane >> 5, rl = lane & 31;
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        const bool more = k0 + GK < g.K;
+        if (more) fetch(k0 + GK);
+        u32x4_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *(const u32x4_t*)&Ah[cur][kh][wm * 64 + i * 32 + rl][0];
+            al[i] = *(const u32x4_t*)&Al[cur][kh][wm * 64 + i * 32 + rl][0];
+            bh[i] = *(const u32x4_t*)&Wh[cur][kh][wn * 64 + i * 32 + rl][0];
+            bl[i] = *(const u32x4_t*)&Wl[cur][kh][wn * 64 + i * 32 + rl][0];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&al[i], *(bf16x8_t*)&bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&ah[i], *(bf16x8_t*)&bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&ah[i], *(bf16x8_t*)&bh[j], acc[i][j], 0, 0, 0);
+            }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+            const float gm = g.gamma ? g.gamma[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = (acc[i][j][r] + bv) * g.scale;
+                if (g.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                v *= gm;
+                if (g.res) v += g.res[(long)(g.res_rows ? m % g.res_rows : m) * g.ldres + n];
+                C[(long)m * g.ldc + n] = v;
+            }
+        }
+}
+
+// 0 = exact f32 MFMA everywhere, 1 = bf16x3 for the [N][K]-weight GEMMs (set per call path: decode 1, encode 0)
+static thread_local int g_gemm_split = 0;
+
 static void gemm_f32(hipStream_t st, bool b_kn, const float* A, const float* W, float* C, int M, int N, int K, long lda,
                      long ldw, long ldc, const float* bias = nullptr, int act = 0, const float* gamma = nullptr,
                      const float* res = nullptr, long ldres = 0, int res_rows = 0, float scale = 1.f, int batch = 1,
@@ -175,7 +300,10 @@ static void gemm_f32(hipStream_t st, bool b_kn, const float* A, const float* W, 
     GemmF32Args g{A, W, C, bias, gamma, res, M, N, K, lda, ldw, ldc, ldres, res_rows, scale, act, batch_inner,
                   sAo, sAi, sWo, sWi, sCo, sCi};
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
+    // [K][N] weights (P.V of the codec attention, the inverse-DFT basis) are bound by their operand traffic, not by
+    // the matrix cores (measured: 430 vs 442 us as bf16x3): they keep the exact kernel
     if (b_kn) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, g);
+    else if (g_gemm_split) hipLaunchKernelGGL(gemm_b3_kernel, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, g);
 }
 
@@ -543,6 +671,7 @@ struct MttsCodec {
     std::vector<int> h_lens, h_lens4;
     int64_t* d_codes = nullptr;
     int *d_lens = nullptr, *d_lens4 = nullptr, *d_err = nullptr;
+    int split_decode = 1;       // decode-direction GEMMs as bf16x3 (MTTS_CODEC_GEMM=f32: exact f32 MFMA)
 };
 
 extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, MttsCodec** out) {
@@ -555,6 +684,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     MttsCodec* k = new MttsCodec();
     k->c = *c;
     k->device = device;
+    if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
     *out = k;
@@ -713,6 +843,7 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
     if (T * c.up_stride > c.dec_max_pos) return cfail(MTTS_EINVAL, "window too long for the acoustic decoder");
     CHK(hipSetDevice(k->device));
     hipStream_t st = (hipStream_t)stream;
+    g_gemm_split = k->split_decode;
     {
         int r = ensure_workspace(k, B, T);
         if (r) return r;
@@ -855,6 +986,7 @@ extern "C" int32_t mtts_codec_tokenize(MttsCodec* k, const float* dev_wav, const
     if (T % (2 * c.down_pool)) return cfail(MTTS_EINVAL, "mel_frames must divide by 2*down_pool");
     CHK(hipSetDevice(k->device));
     hipStream_t st = (hipStream_t)stream;
+    g_gemm_split = 0;            // code ids come out of an argmin: exact f32 products
     const int Tc = T / (2 * c.down_pool), T2 = T / 2;
     {
         int r = ensure_workspace(k, B, std::max(Tc, 1));
@@ -957,7 +1089,9 @@ extern "C" int32_t mtts_codec_tokenize(MttsCodec* k, const float* dev_wav, const
 extern "C" int32_t mtts_k_gemm_f32(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N,
                                    int32_t K, int32_t act, void* stream) {
     if (!A || !W || !C || M < 1 || N < 1 || K < 1 || (K % 4)) return cfail(MTTS_EINVAL, "gemm_f32: K must be a multiple of 4");
-    gemm_f32((hipStream_t)stream, false, A, W, C, M, N, K, K, K, N, bias, act);
+    g_gemm_split = (act >> 8) & 1;              // act | 0x100: the bf16x3 kernel (test / tuning hook)
+    gemm_f32((hipStream_t)stream, false, A, W, C, M, N, K, K, K, N, bias, act & 0xff);
+    g_gemm_split = 0;
     CHK(hipGetLastError());
     return MTTS_OK;
 }

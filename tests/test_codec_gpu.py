@@ -31,6 +31,14 @@ def test_gemm_f32_kernel():
             from scipy.special import erf
             ref = 0.5 * ref * (1 + erf(ref / np.sqrt(2)))
         np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+        # the decode direction's kernel: every product as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate.
+        # Dropped terms are < 2^-16 of a product: error bound relative to sum |a||w| (not to the result's size)
+        c3 = torch.zeros(M, N, device="cuda")
+        mc._check(lib.mtts_k_gemm_f32(at.data_ptr(), wt.data_ptr(), bt.data_ptr(), c3.data_ptr(), M, N, K, act | 0x100, None))
+        torch.cuda.synchronize()
+        bound = 3e-5 * (np.abs(a).astype(np.float64) @ np.abs(w).T.astype(np.float64)) + 1e-6
+        assert (np.abs(c3.cpu().numpy() - ref) <= bound).all()
+        assert np.abs(c3.cpu().numpy() - ref).max() < 2e-4
 
 
 def _load(golden_dir, name):
