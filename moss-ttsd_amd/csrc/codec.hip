@@ -393,6 +393,38 @@ __global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ S
     float* s = S + row * ldT;
     const bool qvalid = tq < len;
     const float NEGV = -3.4028234663852886e38f;
+    if (ldT <= 8 * 256) {
+        // the row stays in registers: one 16-byte read and one write per element, one exp (ldT is a multiple of 16)
+        float4 v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 256 * i + 4 * lane;
+            v[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (j < ldT) {
+                const float4 t = *(const float4*)(s + j);
+                v[i].x = j + 0 < T ? ((qvalid && j + 0 < len) ? t.x : t.x + NEGV) : -INFINITY;
+                v[i].y = j + 1 < T ? ((qvalid && j + 1 < len) ? t.y : t.y + NEGV) : -INFINITY;
+                v[i].z = j + 2 < T ? ((qvalid && j + 2 < len) ? t.z : t.z + NEGV) : -INFINITY;
+                v[i].w = j + 3 < T ? ((qvalid && j + 3 < len) ? t.w : t.w + NEGV) : -INFINITY;
+            }
+            mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {       // columns [T, ldT) hold -inf: exp gives exactly 0 there
+            v[i].x = expf(v[i].x - mx); v[i].y = expf(v[i].y - mx); v[i].z = expf(v[i].z - mx); v[i].w = expf(v[i].w - mx);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 256 * i + 4 * lane;
+            if (j < ldT) *(float4*)(s + j) = make_float4(v[i].x / sum, v[i].y / sum, v[i].z / sum, v[i].w / sum);
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int j = lane; j < T; j += 64) {
         float v = (qvalid && j < len) ? s[j] : s[j] + NEGV;
