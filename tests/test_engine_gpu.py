@@ -380,6 +380,26 @@ def test_decode_fused_and_unfused_qkv_epilogue_agree(monkeypatch):
     assert outs[0][0].shape[1] - (ids.shape[1] - 7) > 100       # the run did cross page boundaries
 
 
+def test_graph_replay_equals_stream_launches(monkeypatch):
+    """mtts_step replays one captured hipGraph per decode step (re-captured when the KV page bound grows); with
+    MTTS_GRAPHS=0 the same launches go straight onto the stream.  Same tokens either way, across a page-bound change."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 71, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = synth.synth_prompts(cfg, 72, 3, 50, 0.4, True)
+    max_length = ids.shape[1] + 600                          # 50 -> 650 tokens: the 8-page bound is crossed
+    layers = [dict(top_k=30, top_p=0.9, temperature=1.0)] * 8
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MTTS_GRAPHS", flag)
+        eng = Engine(cfg, max_batch=4, max_seq_len=768)
+        eng.bind_state_dict(w)
+        outs.append(eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=3))
+        eng.close()
+    assert outs[0].shape[1] - (ids.shape[1] - 7) > 520
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_engine_multi_tile_batch_equals_single_tile(engines):
     """40 dialogues in ONE pass (two 32-row activation tiles share each weight stream) == the same
     dialogues served 32 + 8: per-row results do not depend on the tiling."""
