@@ -33,13 +33,13 @@ void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows
 void launch_pack_rows(const void* src, void* dst, int R, int K, int tiles, hipStream_t st);
 void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st);
 void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
-                       void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st);
+                       void* x, void* xn_packed, int R, int H, float eps, hipStream_t st);
 void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, const void* norm_w, void* xn_packed,
-                       void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st);
+                       void* hlast, const RowMeta* meta, int R, int H, float eps, hipStream_t st);
 void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
                      const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
-                     const int32_t* done, hipStream_t st);
+                     hipStream_t st);
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st);
 void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st);
 int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
@@ -426,10 +426,10 @@ static void prof_end(MttsEngine* e, hipStream_t st, hipEvent_t a) {
     hipEventRecord(a, st);
 }
 
-// ---- one forward pass over R <= 32 rows ---------------------------------------------
+// ---- one forward pass: R rows = decode rows (<= MTTS_RCAP, one dialogue each) or a prefill pass (<= MTTS_PFCAP) ----
 // heads: 0 none, 1 from xn (rows are sequences: decode), 2 from hlast (end of prefill)
 static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d_meta, int R, int pages_bound,
-                        int heads, const int32_t* done, hipStream_t st, int64_t kv_tokens_hint) {
+                        int heads, hipStream_t st, int64_t kv_tokens_hint) {
     const int H = e->H, I = e->I, nq = e->nq, nkv = e->nkv;
     const float eps = e->cfg.rms_norm_eps;
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
@@ -438,7 +438,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     // prefill passes always take the tiled GEMM with a split-K that depends on the shape only: a prompt's
     // hidden states then do not depend on how many rows (other dialogues) share its pass
     const bool tiled = heads != 1;
-    launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, done, st);
+    launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, st);
     for (int n = 0; n < e->L; ++n) {
         Layer& l = e->layers[n];
         uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
@@ -457,7 +457,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
                          (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
         if (!fused)
             launch_qkv_post(e->partial, ks_qkv, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
-                            kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, done, st);
+                            kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, st);
         // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
         // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
         const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
@@ -476,7 +476,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         }
         if (tiled) launch_gemm_tile(EPI_PARTIAL, R, ks_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
         else launch_gemm(EPI_PARTIAL, mb, e->p_o, l.wo, e->attn_p, nq * MTTS_HD, Hp, Hp, e->partial, nullptr, st);
-        launch_resid_norm(e->partial, ks_o, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, done, st);
+        launch_resid_norm(e->partial, ks_o, Hp, e->x, l.ln_post, e->xn, nullptr, d_meta, R, H, eps, st);
         if (tiled) {
             launch_gemm_tile(EPI_SILU, R, 1, l.wgu, e->xn, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_p, st);
             launch_gemm_tile(EPI_PARTIAL, R, ks_d, l.wd, e->act_p, I, Hp, Hp, e->partial, nullptr, st);
@@ -486,8 +486,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         }
         const bool lastl = (n == e->L - 1);
         const void* nw = lastl ? e->final_norm : e->layers[n + 1].ln_in;
-        launch_resid_norm(e->partial, ks_d, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps,
-                          done, st);
+        launch_resid_norm(e->partial, ks_d, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps, st);
     }
     if (heads) {
         const void* xin = e->xn;
@@ -625,7 +624,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     for (size_t off = 0; off < Mpad; off += MTTS_PFCAP) {
         const int rows = (int)std::min<size_t>(MTTS_PFCAP, Mpad - off);     // multiple of MTTS_RCAP
         const bool lastc = off + rows >= Mpad;
-        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, rows, pages_bound, lastc ? 2 : 0, nullptr, st, 0));
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, rows, pages_bound, lastc ? 2 : 0, st, 0));
     }
     e->began = true;
     return MTTS_OK;
@@ -642,7 +641,7 @@ static int step_body(MttsEngine* e, int pages_bound, hipStream_t st, int64_t kvt
     launch_update(e->d_decisions, e->d_declog, e->has_forced ? e->d_forced : nullptr, e->d_tf, e->d_gen, e->d_cur,
                   e->d_seqs, e->d_meta, e->d_bitmaps, e->bm_words, e->d_ls, e->cfg.eos_token_id,
                   e->cfg.speech_pad_token, e->cfg.speech_range_lo, e->cfg.speech_range_hi, st);
-    return forward_rows(e, e->d_cur, e->d_meta, round_up(e->B, 32), pages_bound, 1, &e->d_ls->done, st, kvtok);
+    return forward_rows(e, e->d_cur, e->d_meta, round_up(e->B, 32), pages_bound, 1, st, kvtok);
 }
 
 static int step_graph(MttsEngine* e, int pages, hipGraphExec_t* out) {
@@ -888,7 +887,7 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     const int pages_bound = (n + MTTS_PAGE - 1) / MTTS_PAGE;
     for (size_t off = 0; off < Mpad; off += MTTS_PFCAP)
         TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, (int)std::min<size_t>(MTTS_PFCAP, Mpad - off),
-                         pages_bound, 0, nullptr, st, 0));
+                         pages_bound, 0, st, 0));
     // logits of the dialogue's last prompt token only: heads on a one-row activation tile, copied into its slot
     // (the other slots' logits belong to dialogues that are mid-flight)
     HIPCHK(hipMemsetAsync(e->xh, 0, (size_t)MTTS_MAXR * e->H * 2, st));

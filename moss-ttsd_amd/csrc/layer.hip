@@ -251,24 +251,23 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t* __res
 }
 
 void launch_embed_norm(const int32_t* tokens, const RowMeta* meta, const uint16_t* const* tables, const void* norm_w,
-                       void* x, void* xn_packed, int R, int H, float eps, const int32_t* done, hipStream_t st) {
-    (void)done;   // rows that are not running carry seq < 0 in their RowMeta: no separate stop flag is read
+                       void* x, void* xn_packed, int R, int H, float eps, hipStream_t st) {
+    // rows that are not running carry seq < 0 in their RowMeta: the kernels read no separate stop flag
     hipLaunchKernelGGL(embed_norm_kernel, dim3(R), dim3(256), 0, st, tokens, meta, tables, (const uint16_t*)norm_w,
                        (uint16_t*)x, (uint16_t*)xn_packed, H, eps);
 }
 void launch_resid_norm(const float* partial, int ksplit, int Npad, void* x, const void* norm_w, void* xn_packed,
-                       void* hlast, const RowMeta* meta, int R, int H, float eps, const int32_t* done, hipStream_t st) {
+                       void* hlast, const RowMeta* meta, int R, int H, float eps, hipStream_t st) {
     hipLaunchKernelGGL(resid_norm_kernel, dim3(R), dim3(256), 0, st, partial, ksplit, Npad, (uint16_t*)x,
                        (const uint16_t*)norm_w, (uint16_t*)xn_packed, (uint16_t*)hlast, meta, H, eps);
 }
 void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* meta, const void* qnw, const void* knw,
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
                      const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
-                     const int32_t* done, hipStream_t st) {
+                     hipStream_t st) {
     hipLaunchKernelGGL(qkv_post_kernel, dim3(R, nq + 2 * nkv), dim3(64), 0, st, partial, ksplit, Npad, meta,
                        (const uint16_t*)qnw, (const uint16_t*)knw, (const uint16_t*)cosb, (const uint16_t*)sinb,
                        (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, total_pages, nq, nkv, eps);
-    (void)done;
 }
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int rows, int n, float eps, hipStream_t st) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)w,
