@@ -804,6 +804,134 @@ static int ensure_workspace(MttsCodec* k, int B, int T) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// Fused attention of the codec's transformer layers, decode direction (head_dim 64): softmax(QK^T * hd^-0.5 + mask) V
+// without the [T][T] score matrix ever reaching HBM (the three-launch form moves ~3.4 GB per layer for 8 windows).
+// One wave owns 32 queries and walks the keys 32 at a time, products as bf16x3 on v_mfma_f32_32x32x16_bf16:
+//   S^T[key][q] = K . Q^T       (A = K rows, B = Q^T): lane = query, its 16 registers = 16 of the 32 keys
+//   O^T[d][q]  += V^T . P^T     (A = V^T, B = P^T):    lane = query again
+// so the softmax statistics of a query are in-lane (+ one exchange with lane^32), the running rescale of O is a
+// per-lane scalar, and P feeds the second product straight from the registers it was computed in: the reduction
+// over keys may visit them in any order as long as V^T uses the same one (key of operand slot (g, j) of step s is
+// 16 s + 4 g + (j & 3) + 8 (j >> 2)).  fp32 running max / sum (online softmax), fp32 accumulators.
+// Mask (VarLenAttention, modules.py:84-151): a valid query sees keys < len; a padded query row is uniform over all
+// T keys.  grid = (ceil(T/128), heads, B), block 256 = 4 waves x 32 queries.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float4& a, const float4& b, u32x4_t& hi, u32x4_t& lo) {
+    uint32_t h, l;
+    split2(a.x, a.y, h, l); hi.x = h; lo.x = l;
+    split2(a.z, a.w, h, l); hi.y = h; lo.y = l;
+    split2(b.x, b.y, h, l); hi.z = h; lo.z = l;
+    split2(b.z, b.w, h, l); hi.w = h; lo.w = l;
+}
+
+__global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict__ qkv, float* __restrict__ att,
+                                                         const int* __restrict__ lens, int T, int d, float scale) {
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 5, ql = lane & 31;
+    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    if (blockIdx.x * 128 + wave * 32 >= T) return;
+    const int len = lens[b];
+    const bool qpad = q >= len;                         // padded (or out-of-range) query: uniform over all T keys
+    const long ld = 3L * d;
+    const float* base = qkv + (long)b * T * ld + head * 64;
+    // Q^T operand: 8 consecutive d of this lane's query per 16-deep step, split once
+    u32x4_t qh[4], qlo[4];
+    {
+        const float* qp = base + (long)min(q, T - 1) * ld + 8 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 a = *(const float4*)(qp + 16 * s4), c = *(const float4*)(qp + 16 * s4 + 4);
+            split8(a, c, qh[s4], qlo[s4]);
+        }
+    }
+    f32x16_t o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int kend = qpad ? T : len;                    // every lane of a wave needs keys up to the largest bound
+    int kmax = kend;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    for (int k0 = 0; k0 < kmax; k0 += 32) {
+        // ---- S^T tile: keys k0 + (lane&31) as A rows
+        f32x16_t sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+        {
+            const float* kp = base + d + (long)min(k0 + ql, T - 1) * ld + 8 * g;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float4 a = *(const float4*)(kp + 16 * s4), c = *(const float4*)(kp + 16 * s4 + 4);
+                u32x4_t kh, kl;
+                split8(a, c, kh, kl);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kl, *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh, *(bf16x8_t*)&qlo[s4], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh, *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+            }
+        }
+        // ---- masked scores of this lane's query: register i <-> key k0 + (i&3) + 8*(i>>2) + 4*g
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            float v = qpad ? 0.f : sacc[i] * scale;
+            if (key >= kend) v = -INFINITY;
+            sacc[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);    // no key yet: nothing to rescale
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = (sacc[i] == -INFINITY) ? 0.f : expf(sacc[i] - m_new);
+            sacc[i] = pv;
+            ps += pv;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * corr + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[t][i] *= corr;
+        // ---- O^T += V^T . P^T : two 16-key steps; P operand = registers 8s..8s+7 as they stand
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4_t ph, pl;
+            split8(make_float4(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3]),
+                   make_float4(sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]), ph, pl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // V^T operand: row d = 32 t + (lane&31), slot j <-> key k0 + 16 s2 + 4 g + (j&3) + 8 (j>>2)
+                float vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = min(k0 + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2), T - 1);
+                    vv[j] = base[2 * d + (long)key * ld + 32 * t + ql];
+                }
+                u32x4_t vh, vl;
+                split8(make_float4(vv[0], vv[1], vv[2], vv[3]), make_float4(vv[4], vv[5], vv[6], vv[7]), vh, vl);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vl, *(bf16x8_t*)&ph, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vh, *(bf16x8_t*)&pl, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vh, *(bf16x8_t*)&ph, o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        float* op = att + ((long)b * T + q) * d + head * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) op[32 * t + (i & 3) + 8 * (i >> 2) + 4 * g] = o[t][i] * inv;
+    }
+}
+
 // One pre-LN transformer layer (OmniWhisperTransformerLayer, modules.py:187-205) on x [B*T][d].
 static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p, float* x, float* tmp, float* qkv, float* att,
                              int B, int T, int d, int heads, int ffn, const int* d_lens) {
@@ -818,6 +946,17 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln1w, ln1b, tmp, rows, d, 1e-5f,
                        (const int*)nullptr, T, (long)d);
     gemm_f32(st, false, tmp, wqkv, qkv, rows, 3 * d, d, d, d, 3 * d, bqkv);
+    if (g_gemm_split && hd == 64) {
+        // decode direction: one fused launch, the score matrix stays on chip
+        hipLaunchKernelGGL(codec_attn_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, (const float*)qkv, att,
+                           d_lens, T, d, 1.0f / sqrtf((float)hd));
+        gemm_f32(st, false, att, wo, x, rows, d, d, d, d, d, bo, 0, nullptr, x, d);          // x += out_proj(att)
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln2w, ln2b, tmp, rows, d, 1e-5f,
+                           (const int*)nullptr, T, (long)d);
+        gemm_f32(st, false, tmp, w1, k->big, rows, ffn, d, d, d, ffn, b1, 1);
+        gemm_f32(st, false, k->big, w2, x, rows, d, ffn, ffn, ffn, d, b2, 0, nullptr, x, d);  // x += fc2(gelu(fc1))
+        return 0;
+    }
     // S[b,h] = (q k^T) * hd^-0.5   (the reference scales q before the product, modules.py:131)
     gemm_f32(st, false, qkv, qkv + d, k->scores, T, T, hd, 3 * d, 3 * d, ldT, nullptr, 0, nullptr, nullptr, 0, 0,
              1.0f / sqrtf((float)hd), B * heads, heads, (long)T * 3 * d, hd, (long)T * 3 * d, hd, (long)heads * T * ldT,
