@@ -855,21 +855,41 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
     int kmax = kend;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    // software pipeline: the K rows of the next tile and the V values of the current one are requested before the
+    // current tile's products and softmax, so their L2 latency overlaps the arithmetic (2 waves per SIMD only)
+    float4 kreg[8];
+    auto load_k = [&](int k0) {
+        const float* kp = base + d + (long)min(k0 + ql, T - 1) * ld + 8 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { kreg[2 * s4] = *(const float4*)(kp + 16 * s4); kreg[2 * s4 + 1] = *(const float4*)(kp + 16 * s4 + 4); }
+    };
+    load_k(0);
     for (int k0 = 0; k0 < kmax; k0 += 32) {
+        // ---- V^T operand values of this tile: row d = 32 t + (lane&31), slot j <-> key k0 + 16 s2 + 4 g + (j&3) + 8 (j>>2)
+        float vv[2][2][8];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = min(k0 + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2), T - 1);
+                    vv[s2][t][j] = base[2 * d + (long)key * ld + 32 * t + ql];
+                }
         // ---- S^T tile: keys k0 + (lane&31) as A rows
         f32x16_t sacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
         {
-            const float* kp = base + d + (long)min(k0 + ql, T - 1) * ld + 8 * g;
+            u32x4_t kh[4], kl[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) split8(kreg[2 * s4], kreg[2 * s4 + 1], kh[s4], kl[s4]);
+            if (k0 + 32 < kmax) load_k(k0 + 32);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const float4 a = *(const float4*)(kp + 16 * s4), c = *(const float4*)(kp + 16 * s4 + 4);
-                u32x4_t kh, kl;
-                split8(a, c, kh, kl);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kl, *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh, *(bf16x8_t*)&qlo[s4], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh, *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kl[s4], *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh[s4], *(bf16x8_t*)&qlo[s4], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&kh[s4], *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
             }
         }
         // ---- masked scores of this lane's query: register i <-> key k0 + (i&3) + 8*(i>>2) + 4*g
@@ -907,15 +927,9 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
                    make_float4(sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]), ph, pl);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                // V^T operand: row d = 32 t + (lane&31), slot j <-> key k0 + 16 s2 + 4 g + (j&3) + 8 (j>>2)
-                float vv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = min(k0 + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2), T - 1);
-                    vv[j] = base[2 * d + (long)key * ld + 32 * t + ql];
-                }
                 u32x4_t vh, vl;
-                split8(make_float4(vv[0], vv[1], vv[2], vv[3]), make_float4(vv[4], vv[5], vv[6], vv[7]), vh, vl);
+                split8(make_float4(vv[s2][t][0], vv[s2][t][1], vv[s2][t][2], vv[s2][t][3]),
+                       make_float4(vv[s2][t][4], vv[s2][t][5], vv[s2][t][6], vv[s2][t][7]), vh, vl);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vl, *(bf16x8_t*)&ph, o[t], 0, 0, 0);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vh, *(bf16x8_t*)&pl, o[t], 0, 0, 0);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vh, *(bf16x8_t*)&ph, o[t], 0, 0, 0);
