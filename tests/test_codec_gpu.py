@@ -49,9 +49,13 @@ def _load(golden_dir, name):
     return z, cfg, w, codes
 
 
-@pytest.mark.parametrize("name", ["codec_T40", "codec_ragged_1win", "codec_T600", "codec_full_T24"])
-def test_codec_matches_reference_fixture(golden_dir, name):
+@pytest.mark.parametrize("name,gemm", [("codec_T40", None), ("codec_ragged_1win", None), ("codec_T600", None),
+                                       ("codec_full_T24", None), ("codec_ragged_1win", "f32"), ("codec_full_T24", "f32")])
+def test_codec_matches_reference_fixture(golden_dir, monkeypatch, name, gemm):
+    """Default: bf16x3 GEMMs + fused attention; gemm="f32": the exact-f32 kernels (MTTS_CODEC_GEMM=f32)."""
     from mtts.codec import CodecEngine
+    if gemm:
+        monkeypatch.setenv("MTTS_CODEC_GEMM", gemm)
     z, cfg, w, codes = _load(golden_dir, name)
     eng = CodecEngine(cfg)
     eng.bind_state_dict(w)
