@@ -813,7 +813,7 @@ static int ensure_workspace(MttsCodec* k, int B, int T) {
 // so the softmax statistics of a query are in-lane (+ one exchange with lane^32), the running rescale of O is a
 // per-lane scalar, and P feeds the second product straight from the registers it was computed in: the reduction
 // over keys may visit them in any order as long as V^T uses the same one (key of operand slot (g, j) of step s is
-// 16 s + 4 g + (j & 3) + 8 (j >> 2)).  fp32 running max / sum (online softmax), fp32 accumulators.
+// 16 s + 4 g + (j & 3) + 8 (j >> 2)).  fp32 running max / sum (online softmax, hardware exp), fp32 accumulators.
 // Mask (VarLenAttention, modules.py:84-151): a valid query sees keys < len; a padded query row is uniform over all
 // T keys.  grid = (ceil(T/128), heads, B), block 256 = 4 waves x 32 queries.
 // ------------------------------------------------------------------------------------
@@ -867,14 +867,17 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
     for (int k0 = 0; k0 < kmax; k0 += 32) {
         // ---- V^T operand values of this tile: row d = 32 t + (lane&31), slot j <-> key k0 + 16 s2 + 4 g + (j&3) + 8 (j>>2)
         float vv[2][2][8];
+        const bool tail = k0 + 32 > T;                                       // only the last tile clamps its keys
+        const float* vrow = base + 2 * d + (long)(k0 + 4 * g) * ld + ql;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int key = min(k0 + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2), T - 1);
-                    vv[s2][t][j] = base[2 * d + (long)key * ld + 32 * t + ql];
+                    const int koff = 16 * s2 + (j & 3) + 8 * (j >> 2);          // + 4 g + k0: this lane's key
+                    const int key = tail ? min(k0 + 4 * g + koff, T - 1) - (k0 + 4 * g) : koff;
+                    vv[s2][t][j] = vrow[(long)key * ld + 32 * t];
                 }
         // ---- S^T tile: keys k0 + (lane&31) as A rows
         f32x16_t sacc;
@@ -904,11 +907,11 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float corr = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);    // no key yet: nothing to rescale
+        const float corr = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);    // no key yet: nothing to rescale
         float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float pv = (sacc[i] == -INFINITY) ? 0.f : expf(sacc[i] - m_new);
+            const float pv = (sacc[i] == -INFINITY) ? 0.f : __expf(sacc[i] - m_new);
             sacc[i] = pv;
             ps += pv;
         }
