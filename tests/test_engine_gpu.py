@@ -309,6 +309,32 @@ def test_long_ragged_prefill_vs_oracle(monkeypatch, mfma_from_pages):
     eng.close()
 
 
+@pytest.mark.parametrize("nq,nkv", [(2, 2), (4, 1)])
+def test_gqa_group_sizes_vs_oracle(nq, nkv):
+    """GQA groups 1 (multi-head) and 4: the attention kernels (decode fused / unfused, prefill tiles) are templated on
+    the group size; the reference fixtures cover 2 and 4.  Oracle's greedy run replayed, 90 steps (one page boundary),
+    prompts of 70..140 tokens (three prefill tiles)."""
+    from mtts.engine import Engine
+    cfg = synth.tiny(num_attention_heads=nq, num_key_value_heads=nkv)
+    w = synth.synth_weights(cfg, 81, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = synth.synth_prompts(cfg, 82, 3, 140, 0.4, True)
+    max_length = ids.shape[1] + 90
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    gold = orc.generate(ids, mask, max_length)
+    margins = np.stack(orc.last_margins)
+    T = ids.shape[1]
+    eng = Engine(cfg, max_batch=4, max_seq_len=320)
+    eng.bind_state_dict(w)
+    out, dec = eng.generate(ids, mask, max_length, forced=gold)
+    eng.close()
+    want = gold[:, T - 7:].transpose(1, 0, 2)
+    assert dec.shape == want.shape
+    safe = margins >= MARGIN_OK
+    assert safe.mean() > 0.8
+    bad = np.argwhere(safe & (dec != want))
+    assert len(bad) == 0, bad[:10]
+
+
 def _rand_weights_on_gpu(cfg, seed):
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
