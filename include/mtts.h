@@ -140,12 +140,17 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 
 /* measurement hooks (bench / profiling only, never on the product path) */
 int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len);   /* also fills the KV pages with pseudo-random bf16 */
+/* train of `iters` launches of one decode attention pass (1 scores, 2 P.V) at the current state; when the product would
+ * run the fused q/k/v epilogue at this size the train does too and overwrites the current position's K/V rows:
+ * call it only when no further step follows */
 int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters, float* avg_ms, int64_t* bytes_per_launch);
+/* waves > 0: skinny decode GEMM (32 rows) with that decomposition; waves < 0: the tiled prefill GEMM on -waves rows */
 int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t ksplit, int32_t waves, int32_t copies,
                           int32_t iters, float* avg_us);
 
 /* ---- per-kernel entry points (unit tests; device pointers) ---------------- */
-/* Y[32,N] = X[32,K] * W[N,K]^T, bf16 in, fp32 accumulate, bf16 out. */
+/* Y[M,N] = X[M,K] * W[N,K]^T, bf16 in, fp32 accumulate, bf16 out.  M <= 128: skinny decode kernel; 128 < M <= 512:
+ * tiled prefill kernel. */
 int32_t mtts_k_gemm_bf16(const void* dev_w, const void* dev_x, void* dev_y,
                          int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream);
 /* RMSNorm (Qwen3RMSNorm, modeling_qwen3.py:59-64): x,w bf16 -> y bf16, rows x n. */
@@ -195,7 +200,8 @@ int32_t mtts_codec_check(MttsCodec* c, void* stream);
  * host_lens int32 [B]; dev_codes int64 [nq][B][375]; host_code_lens int32 [B] (out).  Synchronous. */
 int32_t mtts_codec_tokenize(MttsCodec* c, const float* dev_wav, const int32_t* host_lens, int32_t B, int32_t nsamp,
                             int64_t* dev_codes, int32_t* host_code_lens, void* stream);
-/* unit test: C[M,N] = act(A[M,K] * W[N,K]^T + bias), exact-f32 MFMA */
+/* unit test: C[M,N] = act(A[M,K] * W[N,K]^T + bias); act 0 none, 1 GELU(erf); act | 0x100: the decode direction's
+ * bf16x3 kernel instead of the exact-f32 MFMA */
 int32_t mtts_k_gemm_f32(const float* dev_a, const float* dev_w, const float* dev_bias, float* dev_c,
                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
 

@@ -68,7 +68,7 @@ struct QkvFuse {
     float eps;
 };
 
-// Per-row metadata of one forward pass (R <= 32 rows).
+// Per-row metadata of one forward pass.
 struct RowMeta {
     int32_t seq;     // sequence slot (page-table row), -1 = inactive row
     int32_t pos;     // position of this token = its index among the sequence's real tokens

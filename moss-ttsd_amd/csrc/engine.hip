@@ -766,7 +766,8 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
         e->has_forced = true;
         e->max_steps = std::min(e->max_steps, forced_len - base);
     }
-    // run ahead of the device in small batches; `done` on the device turns later steps into no-ops
+    // run ahead of the device in small batches; once every dialogue has finished the device marks all rows idle and
+    // the steps still in flight do no attention and change no state
     int done = 0, steps = 0;
     while (!done && e->steps_issued < e->max_steps) {
         TRY(issue_steps(e, 8, st));
