@@ -187,23 +187,26 @@ __device__ __forceinline__ void split2(float x, float y, uint32_t& hi, uint32_t&
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
-__global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
-    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][2][GT][8], Al[2][2][GT][8], Wh[2][2][GT][8], Wl[2][2][GT][8];
+// NJ = 32-column tiles per wave: 2 -> 128 x 128 block (3 blocks per CU; the one in use), 4 -> 128 x 256 block.
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void gemm_b3_kernel(GemmF32Args g) {
+    constexpr int BN = 64 * NJ;                  // block columns
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][2][GT][8], Al[2][2][GT][8], Wh[2][2][BN][8], Wl[2][2][BN][8];
     const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
     const float* A = g.A + zo * g.sAo + zi * g.sAi;
     const float* W = g.W + zo * g.sWo + zi * g.sWi;
     float* C = g.C + zo * g.sCo + zi * g.sCi;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16_t acc[2][2];
+    f32x16_t acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float ra[2][4], rw[2][4];
+    float ra[2][4], rw[NJ][4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -211,12 +214,20 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
             const int row = idx >> 2, kq = idx & 3;
             const int k = k0 + 4 * kq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ra[i][j] = 0.f; rw[i][j] = 0.f; }
+            for (int j = 0; j < 4; ++j) ra[i][j] = 0.f;
             if (m0 + row < g.M) {
                 const float* p = A + (long)(m0 + row) * g.lda + k;
                 if (k + 3 < g.K) { const float4 t = *(const float4*)p; ra[i][0] = t.x; ra[i][1] = t.y; ra[i][2] = t.z; ra[i][3] = t.w; }
                 else { for (int j = 0; j < 4; ++j) if (k + j < g.K) ra[i][j] = p[j]; }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, kq = idx & 3;
+            const int k = k0 + 4 * kq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rw[i][j] = 0.f;
             if (n0 + row < g.N) {
                 const float* p = W + (long)(n0 + row) * g.ldw + k;
                 if (k + 3 < g.K) { const float4 t = *(const float4*)p; rw[i][0] = t.x; rw[i][1] = t.y; rw[i][2] = t.z; rw[i][3] = t.w; }
@@ -234,6 +245,12 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
             split2(ra[i][2], ra[i][3], h1, l1);
             *(u32x2_t*)&Ah[buf][kh][row][off] = u32x2_t{h0, h1};
             *(u32x2_t*)&Al[buf][kh][row][off] = u32x2_t{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, kq = idx & 3, kh = kq >> 1, off = 4 * (kq & 1);
+            uint32_t h0, h1, l0, l1;
             split2(rw[i][0], rw[i][1], h0, l0);
             split2(rw[i][2], rw[i][3], h1, l1);
             *(u32x2_t*)&Wh[buf][kh][row][off] = u32x2_t{h0, h1};
@@ -248,18 +265,21 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
     for (int k0 = 0; k0 < g.K; k0 += GK) {
         const bool more = k0 + GK < g.K;
         if (more) fetch(k0 + GK);
-        u32x4_t ah[2], al[2], bh[2], bl[2];
+        u32x4_t ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             ah[i] = *(const u32x4_t*)&Ah[cur][kh][wm * 64 + i * 32 + rl][0];
             al[i] = *(const u32x4_t*)&Al[cur][kh][wm * 64 + i * 32 + rl][0];
-            bh[i] = *(const u32x4_t*)&Wh[cur][kh][wn * 64 + i * 32 + rl][0];
-            bl[i] = *(const u32x4_t*)&Wl[cur][kh][wn * 64 + i * 32 + rl][0];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bh[j] = *(const u32x4_t*)&Wh[cur][kh][wn * 32 * NJ + j * 32 + rl][0];
+            bl[j] = *(const u32x4_t*)&Wl[cur][kh][wn * 32 * NJ + j * 32 + rl][0];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&al[i], *(bf16x8_t*)&bh[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&ah[i], *(bf16x8_t*)&bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&ah[i], *(bf16x8_t*)&bh[j], acc[i][j], 0, 0, 0);
@@ -271,8 +291,8 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmF32Args g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * 32 * NJ + j * 32 + (lane & 31);
             if (n >= g.N) continue;
             const float bv = g.bias ? g.bias[n] : 0.f;
             const float gm = g.gamma ? g.gamma[n] : 1.f;
@@ -303,7 +323,9 @@ static void gemm_f32(hipStream_t st, bool b_kn, const float* A, const float* W, 
     // [K][N] weights (P.V of the codec attention, the inverse-DFT basis) are bound by their operand traffic, not by
     // the matrix cores (measured: 430 vs 442 us as bf16x3): they keep the exact kernel
     if (b_kn) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, g);
-    else if (g_gemm_split) hipLaunchKernelGGL(gemm_b3_kernel, grid, dim3(256), 0, st, g);
+    // (a 128 x 256 block, NJ = 4, was measured too: fewer operand bytes per MFMA but 2 blocks per CU instead of 3 --
+    // faster only on the 512 -> 4096 Vocos expansion and slower end to end)
+    else if (g_gemm_split) hipLaunchKernelGGL(gemm_b3_kernel<2>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, g);
 }
 
