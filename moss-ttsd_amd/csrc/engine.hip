@@ -145,7 +145,7 @@ struct MttsEngine {
     uint64_t seed = 0;
     bool began = false, has_forced = false;
     // decode-step graphs: one captured step per (rows, KV page bound, ...) key, replayed by mtts_step
-    struct StepGraph { int B, pages, forced, ch0; uint64_t seed; hipGraphExec_t exec; };
+    struct StepGraph { int B, pages, forced, ch0; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
@@ -647,7 +647,7 @@ static int step_body(MttsEngine* e, int pages_bound, hipStream_t st, int64_t kvt
 static int step_graph(MttsEngine* e, int pages, hipGraphExec_t* out) {
     const int forced = e->has_forced ? 1 : 0;
     for (auto& g : e->graphs)
-        if (g.B == e->B && g.pages == pages && g.forced == forced && g.ch0 == e->ch0_sampled && g.seed == e->seed) {
+        if (g.B == e->B && g.pages == pages && g.forced == forced && g.ch0 == e->ch0_sampled) {
             *out = g.exec;
             return MTTS_OK;
         }
@@ -663,7 +663,7 @@ static int step_graph(MttsEngine* e, int pages, hipGraphExec_t* out) {
     hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     HIPCHK(ie);
-    e->graphs.push_back({e->B, pages, forced, e->ch0_sampled, e->seed, exec});
+    e->graphs.push_back({e->B, pages, forced, e->ch0_sampled, exec});
     *out = exec;
     return MTTS_OK;
 }
