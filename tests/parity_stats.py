@@ -1,5 +1,6 @@
 """Agreement of the HIP engine with the reference's greedy runs over ALL decisions (no margin gate), per fixture.
-GPU box only.  Writes profiles/r01_parity_stats.json."""
+and the codec decoder's waveform error against the reference's fixtures.  GPU box only.
+Writes gpurun_out/r01_parity_stats.json and gpurun_out/r01_codec_parity_stats.json (copied to profiles/)."""
 import json, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "moss-ttsd_amd")); sys.path.insert(0, ROOT)
@@ -38,3 +39,30 @@ tot = {k: sum(v[k] for v in out.values()) for k in next(iter(out.values()))}
 out["total"] = tot
 print("total", tot)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r01_parity_stats.json"), "w"), indent=1)
+
+# ---- codec decoder: waveform RMS error against the reference's fixtures, both GEMM modes ------------------------
+import torch
+from mtts import synth_codec
+from mtts.codec import CodecEngine
+
+codec = {}
+for mode in ("bf16x3", "f32"):
+    os.environ["MTTS_CODEC_GEMM"] = mode
+    for name in ["codec_T40", "codec_ragged_1win", "codec_T600", "codec_full_T24"]:
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        cfg = json.loads(str(z["cfg"]))
+        w = synth_codec.synth_weights(cfg, int(z["seed"]))
+        codes = synth_codec.synth_codes(cfg, int(z["seed"]) + 1, list(z["lengths"]))
+        eng = CodecEngine(cfg)
+        eng.bind_state_dict(w)
+        wavs = [x.cpu().numpy() for x in eng.decode([torch.from_numpy(c) for c in codes])]
+        eng.close()
+        stride = int(z["stride"])
+        errs, sig = [], []
+        for i, wv in enumerate(wavs):
+            ref = z[f"wav{i}_sub"].astype(np.float64)
+            errs.append(float(np.sqrt(np.mean((wv[::stride].astype(np.float64) - ref) ** 2))))
+            sig.append(float(np.sqrt(np.mean(ref ** 2))))
+        codec.setdefault(name, {})[mode] = {"max_rms_error": max(errs), "signal_rms": max(sig)}
+        print(name, mode, codec[name][mode])
+json.dump(codec, open(os.path.join(ROOT, "gpurun_out", "r01_codec_parity_stats.json"), "w"), indent=1)
