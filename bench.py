@@ -104,6 +104,29 @@ def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
     return step_time, per_layer, min(t_heads)
 
 
+def host_cores():
+    """CPU threads the numpy oracle can actually use here: BLAS pool size, capped by the affinity mask and the cgroup quota."""
+    n = os.cpu_count() or 1
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        if info:
+            n = max(i["num_threads"] for i in info)
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=32):
     """End-to-end figure: prefill + every decode step run so far + codec decode of ALL the
     frames this run generated (full-depth XY_Tokenizer decoder, 30 s windows / 20 s stride as the reference)."""
@@ -358,11 +381,7 @@ def main():
             eng.close()
             out["codec_decode"] = codec_leg(device)
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                import threadpoolctl
-                cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) if threadpoolctl.threadpool_info() else os.cpu_count()
-            except Exception:
-                cores = os.cpu_count()
+            cores = host_cores()
             st_time, per_layer, heads_t = cpu_baseline(cfg, B, L)
             out["cpu_baseline"] = {"value": B * 8 / st_time, "unit": "codec_tokens/s", "cores": cores, "kind": "port",
                                    "sample": f"numpy oracle, 1 of {cfg['num_hidden_layers']} layers at full width + 8 heads, "
