@@ -13,7 +13,7 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 #define MTTS_WAVE 64
 #define MTTS_MAXR 32          // rows per MFMA N-tile (one activation fragment tile)
 #define MTTS_RCAP 128         // dialogue slots; rows of a decode pass (up to 4 activation tiles share one weight stream)
-#define MTTS_PFCAP 512        // rows of a prefill pass (tiled GEMM); also the row stride of the split-K slabs
+#define MTTS_PFCAP 2048       // rows of a prefill pass (tiled GEMM); also the row stride of the split-K slabs
 #define MTTS_PAGE 64          // tokens per KV page
 #define MTTS_HD 128           // head_dim the kernels are written for
 #define ATT_PB 8              // KV pages per pass-B chunk, decode rows (4 waves x 2 pages)

@@ -435,17 +435,18 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
     const int Hp = round_up(H, 32);
     const int mb = (R + 31) / 32;                    // activation row tiles sharing each weight stream
-    // prefill passes always take the tiled GEMM with a split-K that depends on the shape only: a prompt's
-    // hidden states then do not depend on how many rows (other dialogues) share its pass
+    // prefill passes always take the tiled GEMM with a split-K that depends on the shape only (chosen for a
+    // 1024-row pass: good from one dialogue's prompt up to a full pass): a prompt's hidden states then do not
+    // depend on how many rows (other dialogues) share its pass
     const bool tiled = heads != 1;
     launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, st);
     for (int n = 0; n < e->L; ++n) {
         Layer& l = e->layers[n];
         uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
         uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
-        const int ks_qkv = tiled ? mtts_tile_ksplit(e->qkv_rows, H, MTTS_PFCAP) : e->p_qkv.ksplit;
-        const int ks_o = tiled ? mtts_tile_ksplit(Hp, nq * MTTS_HD, MTTS_PFCAP) : e->p_o.ksplit;
-        const int ks_d = tiled ? mtts_tile_ksplit(Hp, I, MTTS_PFCAP) : e->p_d.ksplit;
+        const int ks_qkv = tiled ? mtts_tile_ksplit(e->qkv_rows, H, 1024) : e->p_qkv.ksplit;
+        const int ks_o = tiled ? mtts_tile_ksplit(Hp, nq * MTTS_HD, 1024) : e->p_o.ksplit;
+        const int ks_d = tiled ? mtts_tile_ksplit(Hp, I, 1024) : e->p_d.ksplit;
         if (tiled) launch_gemm_tile(EPI_PARTIAL, R, ks_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         else launch_gemm(EPI_PARTIAL, mb, e->p_qkv, l.wqkv, e->xn, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, st);
         // decode rows (one dialogue each): the q/k/v epilogue runs inside the attention kernels; prefill passes
@@ -978,7 +979,7 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 
 // ---- per-kernel entry points --------------------------------------------------------
 int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream) {
-    if (!w || !x || !y || M < 1 || M > MTTS_PFCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=512, K%%16==0");
+    if (!w || !x || !y || M < 1 || M > MTTS_PFCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=MTTS_PFCAP, K%%16==0");
     hipStream_t st = S(stream);
     int Npad = round_up(N, 32);
     void *wp = nullptr, *xp = nullptr;
@@ -1115,7 +1116,7 @@ extern "C" int32_t mtts_k_gemm_bench(int32_t N, int32_t K, int32_t epi, int32_t 
     if (N % 32 || K % 16 || copies < 1 || iters < 1 || !avg_us) return fail(MTTS_EINVAL, "gemm_bench: bad argument");
     // waves < 0: the tiled prefill kernel on -waves rows (<= MTTS_PFCAP), split-K as given
     const int tile_rows = waves < 0 ? -waves : 0;
-    if (tile_rows > MTTS_PFCAP) return fail(MTTS_EINVAL, "gemm_bench: at most 512 rows");
+    if (tile_rows > MTTS_PFCAP) return fail(MTTS_EINVAL, "gemm_bench: at most MTTS_PFCAP rows");
     GemmPlan p = (ksplit > 0 && waves > 0) ? mtts_plan_gemm_forced(N, K, ksplit, waves) : mtts_plan_gemm(N, K, tile_rows ? std::max(ksplit, 1) : ksplit);
     if (tile_rows) p.ksplit = std::max(ksplit, 1);
     std::vector<uint16_t*> w(copies, nullptr);

@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "moss-ttsd_amd"))
 from mtts import capi
 lib = capi.lib()
-R = 512
+R = int(os.environ.get("TILE_ROWS", 512))
 for name, N, K, epi, kss in [("qkv", 4096, 2048, 0, (1, 2, 4)), ("o", 2048, 2048, 0, (1, 2, 4, 8)), ("gateup", 12288, 2048, 2, (1,)),
                              ("down", 2048, 6144, 0, (1, 2, 4, 8))]:
     res = []
