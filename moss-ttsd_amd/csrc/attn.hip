@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     }
 }
 
-// grid = (R, nq), block 128.  The chunk partials are loaded 8 at a time (independent loads; a loop that adds as it
+// grid = (R, ceil(nq/4)), block 512 = 4 heads x 128 dims.  The chunk partials are loaded 8 at a time (independent loads; a loop that adds as it
 // loads would pay one memory round trip per chunk) and summed in chunk order.
-__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ opart, const RowMeta* __restrict__ meta,
+__global__ __launch_bounds__(512) void attn_combine_kernel(const float* __restrict__ opart, const RowMeta* __restrict__ meta,
                                                            uint16_t* __restrict__ out_packed, int nchunks_max, int nq,
                                                            int pages_per_chunk) {
-    const int r = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    const int r = blockIdx.x, h = blockIdx.y * 4 + (threadIdx.x >> 7), d = threadIdx.x & 127;
+    if (h >= nq) return;
     const RowMeta m = meta[r];
     float s = 0.f;
     const int npages = m.seq >= 0 ? (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE : 0;
@@ -533,7 +534,7 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
         return;
     }
     if (phase == 13) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, (nq + 3) / 4), dim3(512), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_pf, nq, ATT_PF);
         return;
     }
@@ -557,7 +558,7 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
                                (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
     }
     if (phase == 0 || phase == 3)
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, nq), dim3(128), 0, st, (const float*)opart, meta,
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(R, (nq + 3) / 4), dim3(512), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
 }
 

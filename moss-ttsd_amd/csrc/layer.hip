@@ -165,15 +165,16 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(
 //   K page layout: [d/8][token 0..63][8]   (token-major inner: the
 //   score kernel reads one token per lane with no cross-lane reduction)
 //   V page layout: [page][kvh][token pair 0..31][d 0..127][2]  (P.V as v_dot2c against packed p pairs)
-// grid = (R, nq + 2*nkv), block 64 (lane l owns d = l and d = l+64).
+// grid = (R, ceil((nq + 2*nkv)/4)), block 256: one head per wave (lane l owns d = l and d = l+64).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void qkv_post_kernel(
+__global__ __launch_bounds__(256) void qkv_post_kernel(
     const float* __restrict__ partial, int ksplit, int Npad, const RowMeta* __restrict__ meta,
     const uint16_t* __restrict__ qnorm_w, const uint16_t* __restrict__ knorm_w,
     const uint16_t* __restrict__ rope_cos, const uint16_t* __restrict__ rope_sin,
     uint16_t* __restrict__ qbuf /*[R][nq][128]*/, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, int max_pages, int total_pages, int nq, int nkv, float eps) {
-    const int r = blockIdx.x, h = blockIdx.y, l = threadIdx.x;
+    const int r = blockIdx.x, h = blockIdx.y * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (h >= nq + 2 * nkv) return;                       // whole wave
     const int col = h * MTTS_HD;
     const size_t kstride = (size_t)MTTS_PFCAP * Npad;
     const float* p0 = partial + (size_t)r * Npad + col + l;
@@ -265,7 +266,7 @@ void launch_qkv_post(const float* partial, int ksplit, int Npad, const RowMeta* 
                      const void* cosb, const void* sinb, void* qbuf, void* kcache, void* vcache,
                      const int32_t* page_table, int max_pages, int total_pages, int R, int nq, int nkv, float eps,
                      hipStream_t st) {
-    hipLaunchKernelGGL(qkv_post_kernel, dim3(R, nq + 2 * nkv), dim3(64), 0, st, partial, ksplit, Npad, meta,
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(R, (nq + 2 * nkv + 3) / 4), dim3(256), 0, st, partial, ksplit, Npad, meta,
                        (const uint16_t*)qnw, (const uint16_t*)knw, (const uint16_t*)cosb, (const uint16_t*)sinb,
                        (uint16_t*)qbuf, (uint16_t*)kcache, (uint16_t*)vcache, page_table, max_pages, total_pages, nq, nkv, eps);
 }
