@@ -266,13 +266,15 @@ class AsteroidOracle:
 
     # ---- the decode loop (reference modeling_asteroid.py:83-169) ----------
     def generate(self, input_ids, attention_mask, max_length, layers=None,
-                 do_samples=None, seed=0, return_logits=False, max_steps=None, forced=None):
+                 do_samples=None, seed=0, return_logits=False, max_steps=None, forced=None, forced_as_draw=False):
         """input_ids int64 [B,T,8], attention_mask [B,T].  `max_length` is HF's
         generation_config.max_length (counts the T-7 kept prompt slots + new
         tokens).  layers/do_samples mirror generation_config.layers/do_samples.
         forced (test hook): int64 [B,G,8] continuation; each step's own decision is
         recorded, then the forced row is appended instead (teacher-forced replay);
-        returns (ids, decisions[steps,B,8])."""
+        returns (ids, decisions[steps,B,8]).  forced_as_draw (replay of a SAMPLED reference run): the forced row
+        replaces the step's raw draw BEFORE the state machine (which then follows the reference's history, not this
+        run's own draws); the recorded decisions are the raw draws."""
         cfg = self.cfg
         C = cfg["channels"]
         eos, pad = cfg["eos_token_id"], cfg["speech_pad_token"]
@@ -289,6 +291,7 @@ class AsteroidOracle:
         do_samples = do_samples or [False] * C
         logits_log, decisions = [], []
         self.last_margins = []          # relative top-2 gap of every decision, [steps][B,C]
+        self.last_scores = []           # processed scores [steps][C] of [B,V_c] when self.keep_scores is set
         step = 0
         first = True
         while True:
@@ -296,7 +299,15 @@ class AsteroidOracle:
             pos_all = np.cumsum(mask, axis=1) - 1
             pos_all[mask == 0] = 1
             if first:
-                logits = self.forward(ids, pos_all, mask)
+                # long prompts: the prompt is fed in chunks of query rows (each row's arithmetic is its own, so the
+                # chunking only bounds the [S,L] score temporaries)
+                ch = int(getattr(self, "prefill_chunk", 0) or 0)
+                if ch and ids.shape[1] > ch:
+                    for a in range(0, ids.shape[1], ch):
+                        e = min(a + ch, ids.shape[1])
+                        logits = self.forward(ids[:, a:e], pos_all[:, a:e], mask[:, :e])
+                else:
+                    logits = self.forward(ids, pos_all, mask)
                 first = False
             else:
                 logits = self.forward(ids[:, -1:], pos_all[:, -1:], mask)
@@ -312,6 +323,10 @@ class AsteroidOracle:
             mg = np.zeros((B, C), dtype=F32)
             for c in range(C):
                 sc = apply_processors(ids[..., c], logits[c], layers[c])
+                if getattr(self, "keep_scores", False):
+                    if c == 0:
+                        self.last_scores.append([])
+                    self.last_scores[-1].append(sc.copy())
                 if do_samples[c]:
                     nxt[:, c] = sample_from_scores(sc, seed, step, c)
                 else:
@@ -319,6 +334,9 @@ class AsteroidOracle:
                 top2 = np.partition(sc, -2, axis=-1)[:, -2:]
                 mg[:, c] = (top2[:, 1] - top2[:, 0]) / np.maximum(np.abs(top2[:, 1]), F32(1e-6))
             self.last_margins.append(mg)
+            if forced is not None and forced_as_draw:
+                decisions.append(nxt.copy())
+                nxt = forced[:, ids.shape[1]].copy()
             is_speech = (nxt[:, 0] >= lo) & (nxt[:, 0] < hi)
             nas[(~is_speech) & (nas < 0)] = C - 1
             if cur + 1 <= tf_inputs.shape[1]:
@@ -332,7 +350,7 @@ class AsteroidOracle:
             for i in range(C):
                 pd = eos if i == 0 else pad
                 nxt[:, i] = nxt[:, i] * unfinished + pd * (1 - unfinished)
-            if forced is not None:
+            if forced is not None and not forced_as_draw:
                 decisions.append(nxt.copy())
                 nxt = forced[:, ids.shape[1]].copy()
             ids = np.concatenate([ids, nxt[:, None, :]], axis=1)

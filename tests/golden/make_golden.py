@@ -59,6 +59,61 @@ class RefModel(ma.AsteroidTTSInstruct):
             self.lm_heads[i].weight = self.model.embedding_list[i].weight
 
 
+class RefModelSample(RefModel):
+    """The reference model with the three transformers-4.53.2 generation helpers that
+    `CustomMixin._sample` (modeling_asteroid.py:92,112,117) relies on and that 5.x removed or changed, so that the
+    reference's OWN `_sample` body runs unmodified (4.53.2 semantics: `generation/utils.py`
+    `_get_initial_cache_position`, `prepare_inputs_for_generation`, `_update_model_kwargs_for_generation`)."""
+
+    def _get_initial_cache_position(self, seq_length, device, model_kwargs):
+        model_kwargs["cache_position"] = torch.arange(seq_length, device=device)
+        return model_kwargs
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None,
+                                      cache_position=None, **kw):
+        if past_key_values is not None and input_ids.shape[1] != cache_position.shape[0]:
+            input_ids = input_ids[:, cache_position]
+        pos = attention_mask.long().cumsum(-1) - 1
+        pos.masked_fill_(attention_mask == 0, 1)
+        pos = pos[:, -input_ids.shape[1]:]
+        return dict(input_ids=input_ids, attention_mask=attention_mask, position_ids=pos,
+                    past_key_values=past_key_values, use_cache=True, cache_position=cache_position)
+
+    def _update_model_kwargs_for_generation(self, outputs, model_kwargs, **kw):
+        model_kwargs["past_key_values"] = outputs.past_key_values
+        am = model_kwargs["attention_mask"]
+        model_kwargs["attention_mask"] = torch.cat([am, am.new_ones((am.shape[0], 1))], dim=-1)
+        model_kwargs["cache_position"] = model_kwargs["cache_position"][-1:] + 1
+        return model_kwargs
+
+
+@torch.no_grad()
+def real_sample(model, input_ids, attention_mask, max_length, layers=None, do_samples=None, want_scores=False):
+    """Run the reference's real `CustomMixin._sample` (modeling_asteroid.py:53-197) the way `generate()` would call
+    it: per-channel processors from generation_config.layers / do_samples, MaxLength + EOS stopping criteria."""
+    from transformers import GenerationConfig
+    from transformers.generation.stopping_criteria import (EosTokenCriteria, MaxLengthCriteria,
+                                                           StoppingCriteriaList)
+    channels = model.config.channels
+    lay = list(layers or [])
+    lay += [{}] * (channels - len(lay))
+    gc = GenerationConfig(max_length=int(max_length), eos_token_id=model.config.eos_token_id, do_sample=False,
+                          return_dict_in_generate=bool(want_scores), output_scores=bool(want_scores))
+    gc.layers = lay
+    gc.do_samples = list(do_samples) if do_samples is not None else [False] * channels
+    crit = StoppingCriteriaList([MaxLengthCriteria(max_length=int(max_length)),
+                                 EosTokenCriteria(eos_token_id=model.config.eos_token_id)])
+    model.__class__ = RefModelSample
+    out = model._sample(input_ids.clone(), logits_processor=LogitsProcessorList(), stopping_criteria=crit,
+                        generation_config=gc, synced_gpus=False, streamer=None,
+                        attention_mask=attention_mask.clone(), past_key_values=DynamicCache(config=model.config),
+                        use_cache=True)
+    model.__class__ = RefModel
+    if want_scores:
+        return out.sequences.numpy(), out.scores
+    return out.numpy()
+
+
 def build_reference(cfg, weights, dtype):
     hf = ma.AsteroidTTSConfig(
         vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
@@ -222,27 +277,95 @@ def processors_case():
     print("processors: ok")
 
 
+def sampled_case():
+    """A sampled run of the reference's real `_sample` (do_samples all True, top-k/top-p/temperature/repetition penalty):
+    the tokens come from torch.multinomial and cannot be reproduced, but the per-step PROCESSED SCORES (the kept set
+    and its values) given the reference's own history can: they pin the sampled-mode support."""
+    cfg = synth.tiny()
+    wkw = dict(emb_row_sigma=0.6, speech_boost=4.0, eos_boost=2.0)
+    seed = 505
+    w = synth.synth_weights(cfg, seed, bf16=True, **wkw)
+    model = build_reference(cfg, w, torch.bfloat16)
+    ids, mask = synth.synth_prompts(cfg, seed + 1, 2, 30, 0.4, True)
+    ml = ids.shape[1] + 28
+    layers = [dict(repetition_penalty=1.1, temperature=0.9, top_k=20, top_p=0.9)] + \
+             [dict(repetition_penalty=1.05, temperature=1.1, top_k=30, top_p=0.95)] * 7
+    torch.manual_seed(1234)
+    out, scores = real_sample(model, torch.from_numpy(ids), torch.from_numpy(mask), ml, layers, [True] * 8,
+                              want_scores=True)
+    KMAX = 32
+    steps = len(scores)
+    B = ids.shape[0]
+    kept_idx = np.full((steps, B, 8, KMAX), -1, dtype=np.int32)
+    kept_val = np.full((steps, B, 8, KMAX), -np.inf, dtype=np.float32)
+    gap = np.full((steps, B, 8), np.inf, dtype=np.float32)      # relative gap between the last kept and first dropped
+    for s in range(steps):
+        for c in range(8):
+            sc = scores[s][c]
+            for b in range(B):
+                fin = torch.nonzero(torch.isfinite(sc[b])).flatten()
+                assert 0 < len(fin) <= KMAX
+                order = fin[torch.argsort(sc[b][fin], descending=True, stable=True)]
+                kept_idx[s, b, c, :len(order)] = order.numpy()
+                kept_val[s, b, c, :len(order)] = sc[b][order].numpy()
+    d = dict(cfg=json.dumps(cfg), wkw=json.dumps(wkw), seed=seed, input_ids=ids, attention_mask=mask, max_length=ml,
+             out_ids=out, layers=json.dumps(layers), kept_idx=kept_idx, kept_val=kept_val,
+             transformers_version=__import__("transformers").__version__)
+    np.savez_compressed(os.path.join(HERE, "ar_sampled.npz"), **d)
+    print(f"ar_sampled: T={ids.shape[1]} steps={steps} out={out.shape} kept sizes "
+          f"{[(int((kept_idx[:, :, c] >= 0).sum(-1).min()), int((kept_idx[:, :, c] >= 0).sum(-1).max())) for c in (0, 1)]}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["all"]
     if "all" in which or "proc" in which:
         processors_case()
-    if "all" in which or "ar" in which:
-        lo = dict(emb_row_sigma=0.6, speech_boost=3.2, eos_boost=3.2)
-        hi = dict(emb_row_sigma=0.6, speech_boost=4.0, eos_boost=11.0)
+    lo = dict(emb_row_sigma=0.6, speech_boost=3.2, eos_boost=3.2)
+    hi = dict(emb_row_sigma=0.6, speech_boost=4.0, eos_boost=11.0)
+    # name -> (cfg overrides, weight kwargs, seed, batch, prompt_len, audio_frac, max_new, extra kwargs)
+    AR_CASES = {
         # (ii)+(iv)+(i)+(v): text-only prompts, ragged left pads; row 1 picks a non-speech id at
         # step 25 -> EOS flush, then finished-row padding while rows 0/2 run to max_length
-        make_case("ar_text_ragged", {}, lo, 103, 3, 24, 0.0, 40)
+        "ar_text_ragged": ({}, lo, 103, 3, 24, 0.0, 40, {}),
         # two rows flush from step 0 (shortest possible dialogue), one runs on
-        make_case("ar_flush0", {}, lo, 101, 3, 24, 0.0, 24)
+        "ar_flush0": ({}, lo, 101, 3, 24, 0.0, 24, {}),
         # (iii) audio-prompt tail: teacher-forced codes in the first 7 steps
-        make_case("ar_audio_tail", {}, hi, 200, 2, 40, 0.5, 32)
+        "ar_audio_tail": ({}, hi, 200, 2, 40, 0.5, 32, {}),
         # group size 4, single row, no padding
-        make_case("ar_gqa4", dict(num_attention_heads=8, num_key_value_heads=2, hidden_size=512,
-                                  intermediate_size=768), hi, 301, 1, 20, 0.4, 24, ragged=False)
+        "ar_gqa4": (dict(num_attention_heads=8, num_key_value_heads=2, hidden_size=512, intermediate_size=768),
+                    hi, 301, 1, 20, 0.4, 24, dict(ragged=False)),
         # fp32 run of the first case: tight-tolerance pin of the oracle's structure
-        make_case("ar_text_ragged_fp32", {}, lo, 103, 3, 24, 0.0, 40, dtype=torch.float32)
+        "ar_text_ragged_fp32": ({}, lo, 103, 3, 24, 0.0, 40, dict(dtype=torch.float32)),
         # processors on the greedy path (repetition penalty changes the argmax)
-        make_case("ar_rep_penalty", {}, hi, 404, 2, 24, 0.3, 24,
-                  layers=[dict(repetition_penalty=1.3)] * 8)
+        "ar_rep_penalty": ({}, hi, 404, 2, 24, 0.3, 24, dict(layers=[dict(repetition_penalty=1.3)] * 8)),
+    }
+    if "all" in which or "ar" in which:
+        for name, (co, wkw, seed, b, pl, af, mn, kw) in AR_CASES.items():
+            make_case(name, co, wkw, seed, b, pl, af, mn, **kw)
+    if "all" in which or "pin" in which:
+        # The reference's OWN CustomMixin._sample (under RefModelSample's 4.53.2 helper shims) against the restated
+        # loop above and against the committed fixtures: the state machine (EOS flush, teacher forcing, finished-row
+        # padding, stopping rule) is then pinned by the reference's code, not by a restatement of it.
+        rec = {"transformers_version": __import__("transformers").__version__, "cases": {}}
+        for name, (co, wkw, seed, b, pl, af, mn, kw) in AR_CASES.items():
+            dtype = kw.get("dtype", torch.bfloat16)
+            cfg = synth.tiny(**co)
+            w = synth.synth_weights(cfg, seed, bf16=(dtype == torch.bfloat16), **wkw)
+            model = build_reference(cfg, w, dtype)
+            ids, mask = synth.synth_prompts(cfg, seed + 1, b, pl, af, kw.get("ragged", True))
+            ml = ids.shape[1] + mn
+            real = real_sample(model, torch.from_numpy(ids), torch.from_numpy(mask), ml, kw.get("layers"))
+            restated, _, _ = ref_sample_loop(model, torch.from_numpy(ids), torch.from_numpy(mask), ml, kw.get("layers"))
+            z = np.load(os.path.join(HERE, name + ".npz"))
+            ok_r = bool(real.shape == restated.shape and np.array_equal(real, restated))
+            ok_f = bool(real.shape == z["out_ids"].shape and np.array_equal(real, z["out_ids"]))
+            assert ok_r and ok_f, (name, ok_r, ok_f)
+            rec["cases"][name] = {"real_sample_equals_restated_loop": ok_r, "real_sample_equals_fixture": ok_f,
+                                  "out_shape": list(real.shape)}
+            print(f"pin {name}: real _sample == restated loop == fixture, out {real.shape}")
+        with open(os.path.join(HERE, "sample_pin.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    if "all" in which or "sampled" in which:
+        sampled_case()

@@ -144,3 +144,76 @@ def test_delay_pattern_roundtrip():
     c = np.full((2, 9, 8), 1024)
     c[0, :4, 1] = 3
     assert list(ao.find_max_valid_positions(c)) == [3, -1]
+
+
+def test_real_sample_pin_record(golden_dir):
+    """tests/golden/make_golden.py `pin` ran the reference's OWN CustomMixin._sample (modeling_asteroid.py:53-197, under
+    the three 4.53.2 helper shims) on every AR case: it must have equalled both the restated loop that wrote the
+    fixtures and the committed fixtures themselves."""
+    rec = json.load(open(os.path.join(golden_dir, "sample_pin.json")))
+    assert set(rec["cases"]) >= set(CASES + ["ar_text_ragged_fp32"])
+    for name, r in rec["cases"].items():
+        assert r["real_sample_equals_restated_loop"] and r["real_sample_equals_fixture"], name
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        assert list(z["out_ids"].shape) == r["out_shape"]
+
+
+def _sampled_support_check(z, scores_by_step, C=8):
+    """Per-step kept sets (ids with a finite processed score) against the reference's.
+    -> (sets checked, kept tokens in all, tokens in a symmetric difference, largest symmetric difference)."""
+    kept_idx, kept_val = z["kept_idx"], z["kept_val"]
+    checked = tokens = diff = worst = 0
+    for s in range(len(scores_by_step)):
+        for c in range(C):
+            if s < 7 and c >= s + 1:
+                continue                                   # teacher-forced slot: the draw is not used
+            for b in range(kept_idx.shape[1]):
+                ref = kept_idx[s, b, c]
+                n = int((ref >= 0).sum())
+                ref = ref[:n]
+                sc = scores_by_step[s][c][b]
+                got = set(np.nonzero(np.isfinite(sc))[0].tolist())
+                checked += 1
+                tokens += n
+                d = len(got ^ set(ref.tolist()))
+                diff += d
+                worst = max(worst, d)
+                # same values on the common tokens up to bf16 logit noise (4 ulps of the largest)
+                common = np.array([i for i in ref if i in got], dtype=np.int64)
+                rv = kept_val[s, b, c][:n][[i in got for i in ref]]
+                assert len(common) >= n - 3, (s, b, c)
+                assert np.abs(sc[common] - rv).max() <= 2.0 ** -5 * np.abs(rv).max() + 1e-6, (s, b, c)
+    return checked, tokens, diff, worst
+
+
+def test_oracle_sampled_support_matches_reference(golden_dir):
+    """ar_sampled.npz: a SAMPLED run of the reference's real `_sample` (torch.multinomial draws, kept as the forced
+    history) with the processed scores of every step.  Replaying that history, the oracle's processors must keep
+    the same token set with the same values (top-k / top-p boundaries can move on a bf16 logit tie: <= 2 %)."""
+    z = np.load(os.path.join(golden_dir, "ar_sampled.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth.synth_weights(cfg, int(z["seed"]), **json.loads(str(z["wkw"])))
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    orc.keep_scores = True
+    layers = json.loads(str(z["layers"]))
+    ids, dec, _ = orc.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers,
+                               do_samples=[True] * 8, seed=1, forced=z["out_ids"], forced_as_draw=True)
+    assert np.array_equal(ids, z["out_ids"])
+    assert len(orc.last_scores) == z["kept_idx"].shape[0]
+    # the tiny random model's speech channels are nearly flat: the 30th and 31st largest logits often tie in bf16, so
+    # a top-k / top-p boundary token can swap; everything else must be identical
+    checked, tokens, diff, worst = _sampled_support_check(z, orc.last_scores)
+    assert checked > 400 and diff <= 0.02 * tokens and worst <= 3, (checked, tokens, diff, worst)
+    # every draw of the oracle's own Philox stream lies inside the reference's kept set where the sets agree
+    T = z["input_ids"].shape[1]
+    for s in range(dec.shape[0]):
+        for c in range(8):
+            if s < 7 and c >= s + 1:
+                continue
+            for b in range(dec.shape[1]):
+                if z["out_ids"][b, T - 7 + s - 1, 0] == cfg["eos_token_id"] and s > 0:
+                    continue                               # finished row: padding, not a draw
+                ref = z["kept_idx"][s, b, c]
+                if dec[s, b, c] not in ref[ref >= 0]:
+                    got = np.nonzero(np.isfinite(orc.last_scores[s][c][b]))[0]
+                    assert set(got.tolist()) != set(ref[ref >= 0].tolist()), (s, b, c)
