@@ -208,6 +208,48 @@ def codec_leg(device, windows=8, T=375, reps=3):
             "vs_f32_mfma_peak": flop / dt / 157.3e12, "windows_per_call": windows, "codes_per_window": T}
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this script (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) as a child
+    process tree and return its exit code.  The caller has not touched the GPU, and nothing is exec'd over it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, dist, world, rank):
+    """Everything of an N-rank run except the engine: rendezvous, barrier, MAX/SUM reductions, one JSON line from
+    rank 0.  Every rank pretends its K steps took K x 4 ms."""
+    import torch
+    B, K = args.batch, args.steps
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([K * 4e-3 * (1.0 + 0.01 * rank)], dtype=torch.float64)
+    units = torch.tensor([float(B * K * 8)], dtype=torch.float64)
+    ranks = torch.zeros(world, dtype=torch.int64)
+    ranks[rank] = 1
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "audio codec tokens/sec/node (decode, bf16, batch 32 @ 4k ctx)",
+                          "value": float(units.item()) / float(tmax.item()), "unit": "codec_tokens/s",
+                          "n_gpus": world, "ranks": int(ranks.sum().item()), "backend": "gloo", "steps": K,
+                          "warmup": args.warmup, "ms_per_step": float(tmax.item()) / K * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "invalid": "dry run: launcher and collectives only, no engine"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,29 +262,46 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective rehearsal without the engine (CPU, gloo): every rank reports a fixed "
+                         "synthetic step time; checks that --gpus N really runs N ranks (the result is marked invalid)")
     ap.add_argument("--fake-context", action="store_true",
                     help="PMC/profiling runs only: jump to the target context with mtts_debug_set_kv_len instead of "
                          "ramping (cache content is not meaningful; the result is marked invalid)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own (no launcher around it): start N fresh ranks, one per GPU, before this
+    # process makes any GPU call, and hand its exit code back.  Under torchrun (WORLD_SIZE set) this IS one of the ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
-    from mtts import synth
-    from mtts.engine import Engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): "
+                         "refusing to report a number for a different job size")
+    backend = "gloo" if args.dry_run else os.environ.get("MTTS_BENCH_BACKEND", "nccl")   # "gloo" on GPUs only to rehearse N>1 on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MTTS_BENCH_BACKEND", "nccl")       # "gloo" only to rehearse N>1 on a 1-GPU box
-        if backend != "nccl":
-            local = local % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.dry_run:
+            dist.init_process_group("gloo")
         else:
-            dist.init_process_group(backend)
+            if backend != "nccl":
+                local = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            else:
+                dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
+    if args.dry_run:
+        return dry_run(args, dist, world, rank)
+    from mtts import synth
+    from mtts.engine import Engine
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -318,9 +377,11 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     units = torch.tensor([float(B * K * 8)], dtype=torch.float64, device=device)
+    nranks = torch.ones(1, dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
+        dist.all_reduce(nranks, op=dist.ReduceOp.SUM)
     dt_max = float(tmax.item())
     total_ids = float(units.item())
 
@@ -346,7 +407,8 @@ def main():
             traffic = None
         out = {
             "metric": "audio codec tokens/sec/node (decode, bf16, batch 32 @ 4k ctx)",
-            "value": value, "unit": "codec_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "codec_tokens/s", "n_gpus": world, "ranks": int(nranks.item()),
+            "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None, "steps": K, "warmup": W,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights of the ASSUMED 1.7B dims, synthetic prompts)",
             "config": {"workload": "configs[2]: batch 32 synthetic dialogues/GPU, 4k-token KV context, top-k/top-p sampling on 8 channels, decode steps at full context",

@@ -81,3 +81,35 @@ def test_two_rank_gloo_shard_broadcast_gather():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def _bench(*args, env=None):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), env=e, capture_output=True,
+                       text=True, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts 2 ranks itself (here: --dry-run = the launcher,
+    the rendezvous and the MAX/SUM reductions over gloo, no engine); rank 0 prints ONE line whose n_gpus is 2 and
+    whose value is the sum over ranks divided by the slowest rank's time."""
+    rc, out, err = _bench("--gpus", "2", "--dry-run", "--steps", "10", "--batch", "32")
+    assert rc == 0, err[-2000:]
+    assert len(out) == 1
+    o = out[0]
+    assert o["n_gpus"] == 2 and o["ranks"] == 2 and o["steps"] == 10
+    assert abs(o["value"] - 2 * 32 * 10 * 8 / (10 * 4e-3 * 1.01)) < 1e-6 * o["value"]
+    rc, out, err = _bench("--dry-run", "--steps", "10")                     # N=1: no launcher, no process group
+    assert rc == 0 and out[0]["n_gpus"] == 1 and out[0]["ranks"] == 1
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    rc, out, err = _bench("--gpus", "4", "--dry-run", env=dict(WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1",
+                                                              MASTER_PORT=str(_free_port())))
+    assert rc != 0 and not out and "--gpus 4" in err
