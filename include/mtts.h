@@ -55,7 +55,10 @@ typedef struct MttsConfig {
     int32_t max_position;          /* rows in the RoPE table */
     float rms_norm_eps;
     int32_t max_batch;             /* sequences resident at once (1..128: up to 4 MFMA row tiles share each weight stream) */
-    int32_t max_seq_len;           /* real tokens per sequence the KV pool is sized for */
+    int32_t max_seq_len;           /* real tokens one sequence may reach (width of a page-table row) */
+    int32_t kv_pool_pages;         /* 64-token KV pages in the pool shared by all sequences; 0 = max_batch x pages(max_seq_len),
+                                      i.e. every slot can reach max_seq_len at once.  A smaller pool serves short dialogues
+                                      with less memory: pages are taken on demand and returned when a dialogue finishes */
 } MttsConfig;
 
 /* generation_config.layers[i] / do_samples[i] (modeling_asteroid.py:95-106).
@@ -99,7 +102,9 @@ int32_t mtts_weights_ready(MttsEngine* e);   /* 0 when every tensor is bound */
  * sampler[8], seed: sampling stream (Philox4x32-10).
  * Prefills the first T-7 slots, then runs the decode loop on the device until
  * every row is finished.  out: host_out_ids int64 [B, out_capacity, 8] receives
- * [B, T-7+G, 8]; *out_len = T-7+G.
+ * [B, T-7+G, 8]; *out_len = T-7+G.  G can exceed max_length - (T-7) by up to 7: a dialogue whose EOS falls within 7 steps
+ * of max_length still runs its delay-pattern flush, as the reference does (modeling_asteroid.py:165-168); size
+ * out_capacity as max_length + 7.
  * host_forced (verification hook, may be NULL): int64 [B, forced_len, 8] full
  * sequences; when given, every step's own decision is written to
  * host_decisions int64 [G,B,8] and the forced row is appended instead. */
@@ -130,6 +135,18 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* host_ids, i
 int32_t mtts_slot_states(MttsEngine* e, int32_t* host_state, void* stream);
 int32_t mtts_slot_read(MttsEngine* e, int32_t slot, int64_t* host_rows, int32_t capacity_steps, int32_t* n_steps);
 int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream);
+/* Evict the dialogue in `slot` (scheduler mode): it leaves the batch now and its KV pages return to the pool; the host
+ * re-submits it later (tokens are a function of prompt and seed only, so the re-run reproduces them).  Used when
+ * mtts_step reports MTTS_ENOMEM: the pool cannot grow every resident dialogue by another page. */
+int32_t mtts_slot_evict(MttsEngine* e, int32_t slot, void* stream);
+/* KV pool occupancy: pages in the pool, pages free, pages per page-table row. */
+int32_t mtts_kv_pool_state(MttsEngine* e, int32_t* total_pages, int32_t* free_pages, int32_t* max_pages_per_seq);
+/* host_table int32 [max_batch][max_pages_per_seq] (the device page table as the host tracks it), host_n_pages int32 [max_batch]. */
+int32_t mtts_read_page_table(MttsEngine* e, int32_t* host_table, int32_t* host_n_pages);
+/* Forced replay mode of mtts_generate's verification hook: 0 (default) the forced row replaces the state machine's
+ * output (replay of a greedy run); 1 it replaces the step's raw draw before the state machine, host_decisions receives
+ * the raw draws (replay of a SAMPLED reference run: the state follows the reference's history). */
+int32_t mtts_set_forced_mode(MttsEngine* e, int32_t as_draw);
 /* Frames first..first+n-1 as codec codes int64 [8][B][n] on the device (delay pattern undone, generation_utils.py:416-425);
  * `stream` must be ordered after the steps that produced frame first+n+6. */
 int32_t mtts_export_codes(MttsEngine* e, int32_t first, int32_t n, int64_t* dev_codes, void* stream);

@@ -47,7 +47,7 @@ int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* pag
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                 const QkvFuse* fuse, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
-struct LoopState { int32_t step, done, continuous, B, error, gen_cap, pad0, pad1; };
+struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, pad1; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
 #define SAMP_CAND 4096
 #define SAMP_NS 32
@@ -67,6 +67,9 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
 
 void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
                          int cap, hipStream_t st);
+struct PageEdits { int32_t n; int32_t idx[31]; int32_t val[31]; };     // page-table entries handed over as launch arguments
+void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st);
+#define FLUSH_STEPS 7          // a dialogue whose EOS falls within 7 steps of max_length still runs its delay-pattern flush (modeling_asteroid.py:165-168)
 
 // ---- errors -------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -119,7 +122,14 @@ struct MttsEngine {
     size_t layer_stride = 0;           // elements per layer in each cache
     int total_pages = 0, max_pages = 0, nchunks_max = 0;
     int32_t* d_page_table = nullptr;
-    std::vector<int32_t> h_page_table;
+    std::vector<int32_t> h_page_table;  // [slot][max_pages]: pages a slot owns, in position order
+    // KV page pool: pages are handed out on demand as a dialogue's length crosses a page boundary and come back
+    // when it finishes (free list = stack; initial order ascending, or shuffled by MTTS_PAGE_SHUFFLE for the tests)
+    std::vector<int32_t> free_pages;
+    std::vector<int32_t> n_pages;       // pages each slot owns
+    std::vector<char> slot_live;        // host's view: the slot holds a dialogue that may still step
+    PageEdits pending_edits;            // table entries not yet on the device
+    int forced_draw = 0;
     // generation state
     SeqState* d_seqs = nullptr;
     RowMeta* d_meta = nullptr;          // decode rows
@@ -196,6 +206,54 @@ static void free_scratch(SampleScratch& sc) {
     if (sc.full_val) { hipFree(sc.full_val); hipFree(sc.full_idx); }
 }
 
+// ---- KV page pool -----------------------------------------------------------------------------------------------
+// Free list = stack whose top is the lowest page number (a fresh engine hands pages out in ascending order).
+// MTTS_PAGE_SHUFFLE=<seed> (test hook) shuffles it, so that page tables are arbitrary permutations.
+static void pool_reset(MttsEngine* e) {
+    e->free_pages.resize(e->total_pages);
+    for (int i = 0; i < e->total_pages; ++i) e->free_pages[i] = e->total_pages - 1 - i;
+    if (const char* g = getenv("MTTS_PAGE_SHUFFLE")) {
+        uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)atoll(g);
+        for (int i = e->total_pages - 1; i > 0; --i) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(e->free_pages[i], e->free_pages[(x >> 33) % (uint64_t)(i + 1)]);
+        }
+    }
+    std::fill(e->n_pages.begin(), e->n_pages.end(), 0);
+    e->pending_edits.n = 0;
+}
+// table entries reach the device as launch arguments of a one-wave kernel on the caller's stream: ordered with the
+// steps around it, and no host buffer has to outlive the call
+static int pool_flush(MttsEngine* e, hipStream_t st) {
+    if (e->pending_edits.n) {
+        launch_set_pages(e->d_page_table, e->pending_edits, st);
+        e->pending_edits.n = 0;
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+// make slot b own at least `need` pages; MTTS_ENOMEM when the pool runs dry (nothing is taken back)
+static int pool_grow(MttsEngine* e, int b, int need, hipStream_t st) {
+    if (need > e->max_pages) return fail(MTTS_ENOMEM, "slot %d needs %d KV pages, a sequence holds at most %d (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
+    while (e->n_pages[b] < need) {
+        if (e->free_pages.empty()) return fail(MTTS_ENOMEM, "KV page pool exhausted (%d pages of %d tokens): slot %d needs page %d", e->total_pages, MTTS_PAGE, b, e->n_pages[b]);
+        const int page = e->free_pages.back();
+        e->free_pages.pop_back();
+        const int at = b * e->max_pages + e->n_pages[b]++;
+        e->h_page_table[at] = page;
+        if (e->pending_edits.n == 31) TRY(pool_flush(e, st));
+        e->pending_edits.idx[e->pending_edits.n] = at;
+        e->pending_edits.val[e->pending_edits.n++] = page;
+    }
+    return 0;
+}
+// every launch that could touch the slot's pages must have been issued before (stream order protects the rest:
+// the next owner's writes are enqueued after them)
+static void pool_release(MttsEngine* e, int b) {
+    for (int i = e->n_pages[b] - 1; i >= 0; --i) e->free_pages.push_back(e->h_page_table[(size_t)b * e->max_pages + i]);
+    e->n_pages[b] = 0;
+}
+
 int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out) {
     if (!c || !out) return fail(MTTS_EINVAL, "null argument");
     if (c->head_dim != MTTS_HD) return fail(MTTS_EINVAL, "head_dim must be 128 (got %d)", c->head_dim);
@@ -263,13 +321,18 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->join_logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
     // KV pool
     e->max_pages = (c->max_seq_len + MTTS_PAGE - 1) / MTTS_PAGE + 1;
-    e->total_pages = e->max_pages * c->max_batch;
+    e->total_pages = c->kv_pool_pages > 0 ? c->kv_pool_pages : e->max_pages * c->max_batch;
+    if (c->kv_pool_pages < 0) return fail(MTTS_EINVAL, "kv_pool_pages must be >= 0");
     e->nchunks_max = (e->max_pages + ATT_PB - 1) / ATT_PB;
     e->layer_stride = (size_t)e->total_pages * e->nkv * MTTS_PAGE * MTTS_HD;
     TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
     TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
     TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
+    e->n_pages.assign(c->max_batch, 0);
+    e->slot_live.assign(c->max_batch, 0);
+    e->pending_edits.n = 0;
+    pool_reset(e);
     TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_PFCAP * e->nq * e->max_pages * MTTS_PAGE));
     TRY(dalloc(&e->stats, (size_t)MTTS_PFCAP * e->nq * e->max_pages * 2));
     TRY(dalloc(&e->opart, (size_t)MTTS_PFCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
@@ -528,7 +591,9 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     if (T < 8) return fail(MTTS_EINVAL, "T must be >= 8 (delay pattern adds 7 slots)");
     const int base = T - 7;
     if (max_length <= base) return fail(MTTS_EINVAL, "max_length %d leaves no room to generate (prompt slots %d)", max_length, base);
-    const int max_steps = max_length - base;
+    // a dialogue whose EOS falls within 7 steps of max_length keeps stepping until its flush is through
+    // (`unfinished | needs_additional_steps > 0`, modeling_asteroid.py:165-168)
+    const int max_steps = max_length - base + FLUSH_STEPS;
     e->B = B; e->T = T; e->base_length = base; e->max_length = max_length; e->max_steps = max_steps;
     e->seed = seed; e->steps_issued = 0; e->has_forced = false;
     e->n_real.assign(B, 0);
@@ -545,13 +610,15 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         e->n_real[b] = base - p;
         e->max_real = std::max(e->max_real, base - p);
     }
-    // pages
+    // pages: every earlier run has been synchronised by its caller or is ordered before us on `st`; the prompts'
+    // pages are taken now, the rest on demand as the dialogues grow (issue_steps)
+    for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = b < B; }
     for (int b = 0; b < B; ++b) {
-        int need = (e->n_real[b] + max_steps + MTTS_PAGE - 1) / MTTS_PAGE;
-        if (need > e->max_pages) return fail(MTTS_ENOMEM, "row %d needs %d KV pages, pool has %d per sequence (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
-        for (int p = 0; p < e->max_pages; ++p) e->h_page_table[(size_t)b * e->max_pages + p] = b * e->max_pages + p;
+        const int need = (e->n_real[b] + max_steps + MTTS_PAGE - 1) / MTTS_PAGE;
+        if (need > e->max_pages) return fail(MTTS_ENOMEM, "row %d needs %d KV pages, a sequence holds at most %d (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
+        TRY(pool_grow(e, b, (e->n_real[b] + MTTS_PAGE - 1) / MTTS_PAGE, st));
     }
-    HIPCHK(hipMemcpyAsync(e->d_page_table, e->h_page_table.data(), e->h_page_table.size() * 4, hipMemcpyHostToDevice, st));
+    TRY(pool_flush(e, st));
     if (e->max_real + max_steps > e->rope_rows)
         return fail(MTTS_EINVAL, "rope table has %d rows, need %d", e->rope_rows, e->max_real + max_steps);
     // generation buffers
@@ -606,7 +673,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
         for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0, base, max_length, b, 1, seed};
         HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
-        LoopState ls{0, 0, 0, B, 0, e->gen_cap, 0, 0};
+        LoopState ls{0, 0, 0, B, 0, e->gen_cap, e->forced_draw, 0};
         e->continuous = false;
         e->join_step.assign(MTTS_RCAP, 0);
         HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
@@ -672,7 +739,17 @@ static int step_graph(MttsEngine* e, int pages, hipGraphExec_t* out) {
 static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
         if (e->steps_issued >= e->max_steps) break;
-        const int len_bound = e->max_real + e->steps_issued + 1;
+        // this step appends one token per live dialogue at position n_real + steps_issued: take its page if that
+        // crosses a page boundary (the host's view of "live" lags the device by at most one poll: a dialogue that
+        // has just finished may get one page it never writes, returned with the others)
+        int len_bound = 1;
+        for (int b = 0; b < e->B; ++b) {
+            if (!e->slot_live[b]) continue;
+            const int len = e->n_real[b] + e->steps_issued + 1;
+            len_bound = std::max(len_bound, len);
+            TRY(pool_grow(e, b, (len + MTTS_PAGE - 1) / MTTS_PAGE, st));
+        }
+        TRY(pool_flush(e, st));
         const int pages_bound = (len_bound + MTTS_PAGE - 1) / MTTS_PAGE;
         if (e->use_graphs && !e->prof) {
             // the attention grids are sized by the page bound: round it up to a whole pass-B chunk so that one
@@ -685,7 +762,7 @@ static int issue_steps(MttsEngine* e, int n, hipStream_t st) {
             prof_begin(e, PROF_STEP, st, &ev);
             // rough KV token count for the profile's byte figure: every row at its current length
             int64_t kvtok = 0;
-            for (int b = 0; b < e->B; ++b) kvtok += e->n_real[b] + e->steps_issued + 1;
+            for (int b = 0; b < e->B; ++b) if (e->slot_live[b]) kvtok += e->n_real[b] + e->steps_issued + 1;
             TRY(step_body(e, pages_bound, st, kvtok));
             prof_end(e, st, ev);
         }
@@ -706,6 +783,14 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
     HIPCHK(hipMemcpyAsync(e->h_ls, e->d_ls, sizeof(LoopState), hipMemcpyDeviceToHost, S(stream)));
     HIPCHK(hipStreamSynchronize(S(stream)));
     if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 4096 candidate tokens (set top_k so that the k-th score's radix bin holds <= 4096 tokens)", e->h_ls->error);
+    if (!e->continuous) {
+        // static batch (mtts_generate semantics): a finished row only emits padding from here on and never touches
+        // its KV pages again; everything issued so far has completed, so its pages go back to the pool
+        std::vector<SeqState> ss(e->B);
+        HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
+        for (int b = 0; b < e->B; ++b)
+            if (e->slot_live[b] && ss[b].step > 0 && !ss[b].unfinished) { e->slot_live[b] = 0; pool_release(e, b); }
+    }
     if (steps_done) *steps_done = e->h_ls->step;
     if (all_finished) *all_finished = e->h_ls->done;
     return MTTS_OK;
@@ -823,12 +908,12 @@ int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSam
     e->n_real.assign(B, 0);
     e->join_step.assign(MTTS_RCAP, 0);
     e->max_real = 0;
-    for (int b = 0; b < B; ++b)
-        for (int p = 0; p < e->max_pages; ++p) e->h_page_table[(size_t)b * e->max_pages + p] = b * e->max_pages + p;
-    HIPCHK(hipMemcpyAsync(e->d_page_table, e->h_page_table.data(), e->h_page_table.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = 0; }
     std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
     HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
     LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, 0};
+    e->forced_draw = 0;
     HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
     *e->h_ls = ls;
     std::vector<RowMeta> dm(MTTS_RCAP, RowMeta{-1, 0, 0, 0});
@@ -853,9 +938,9 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     if (T < 8) return fail(MTTS_EINVAL, "T must be >= 8");
     const int base = T - 7, n = base;
     if (max_length <= base) return fail(MTTS_EINVAL, "max_length leaves no room to generate");
-    const int max_new = max_length - base;
+    const int max_new = max_length - base + FLUSH_STEPS;      // incl. a delay-pattern flush that starts at max_length
     if (max_new > e->gen_cap) return fail(MTTS_EINVAL, "dialogue may run %d steps, slot storage holds %d", max_new, e->gen_cap);
-    if ((n + max_new + MTTS_PAGE - 1) / MTTS_PAGE > e->max_pages) return fail(MTTS_ENOMEM, "dialogue needs more KV pages than a slot has");
+    if ((n + max_new + MTTS_PAGE - 1) / MTTS_PAGE > e->max_pages) return fail(MTTS_ENOMEM, "dialogue needs more KV pages than a sequence may hold");
     if (n + max_new > e->rope_rows) return fail(MTTS_EINVAL, "rope table too short");
     HIPCHK(hipStreamSynchronize(st));
     {   // the slot must be empty
@@ -863,6 +948,12 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
         HIPCHK(hipMemcpy(&cur, e->d_seqs + slot, sizeof(cur), hipMemcpyDeviceToHost));
         if (cur.active) return fail(MTTS_ESTATE, "slot %d is occupied", slot);
     }
+    // admission: the prompt's pages plus the page its first step may open must be free now
+    if (e->slot_live[slot]) { e->slot_live[slot] = 0; pool_release(e, slot); }      // finished, not collected yet
+    if ((int)e->free_pages.size() < (n + 1 + MTTS_PAGE - 1) / MTTS_PAGE)
+        return fail(MTTS_ENOMEM, "KV page pool: %d pages free, the prompt needs %d", (int)e->free_pages.size(), (n + 1 + MTTS_PAGE - 1) / MTTS_PAGE);
+    TRY(pool_grow(e, slot, (n + MTTS_PAGE - 1) / MTTS_PAGE, st));
+    TRY(pool_flush(e, st));
     const size_t Mpad = ((size_t)n + MTTS_RCAP - 1) / MTTS_RCAP * MTTS_RCAP;
     std::vector<int32_t> toks(Mpad * 8, 0);
     std::vector<RowMeta> metas(Mpad, RowMeta{-1, 0, 0, 0});
@@ -905,7 +996,7 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     HIPCHK(hipStreamSynchronize(st));
     e->n_real[slot] = n - e->steps_issued;          // so that n_real + steps_issued is this dialogue's current length
     e->join_step[slot] = e->steps_issued;
-    e->max_real = *std::max_element(e->n_real.begin(), e->n_real.end());
+    e->slot_live[slot] = 1;
     return MTTS_OK;
 }
 
@@ -919,7 +1010,46 @@ int32_t mtts_slot_states(MttsEngine* e, int32_t* host_state, void* stream) {
     for (int b = 0; b < e->B; ++b) {
         host_state[b * 4 + 0] = ss[b].active; host_state[b * 4 + 1] = ss[b].unfinished;
         host_state[b * 4 + 2] = ss[b].step; host_state[b * 4 + 3] = ss[b].kv_len;
+        // a dialogue that has left the batch (scheduler mode) gives its pages back: the stream is idle, nothing
+        // in flight reads them
+        if (e->continuous && e->slot_live[b] && !ss[b].active) { e->slot_live[b] = 0; pool_release(e, b); }
     }
+    return MTTS_OK;
+}
+
+int32_t mtts_slot_evict(MttsEngine* e, int32_t slot, void* stream) {
+    if (!e || !e->began || !e->continuous) return fail(MTTS_ESTATE, "mtts_sched_open has not run");
+    if (slot < 0 || slot >= e->B) return fail(MTTS_EINVAL, "slot %d out of range", slot);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    SeqState cur;
+    HIPCHK(hipMemcpy(&cur, e->d_seqs + slot, sizeof(cur), hipMemcpyDeviceToHost));
+    cur.active = 0; cur.unfinished = 0;
+    HIPCHK(hipMemcpy(e->d_seqs + slot, &cur, sizeof(cur), hipMemcpyHostToDevice));
+    RowMeta idle{-1, 0, 0, 0};
+    HIPCHK(hipMemcpy(e->d_meta + slot, &idle, sizeof(idle), hipMemcpyHostToDevice));
+    if (e->slot_live[slot]) { e->slot_live[slot] = 0; pool_release(e, slot); }
+    return MTTS_OK;
+}
+
+int32_t mtts_kv_pool_state(MttsEngine* e, int32_t* total_pages, int32_t* free_pages, int32_t* max_pages_per_seq) {
+    if (!e) return fail(MTTS_EINVAL, "null engine");
+    if (total_pages) *total_pages = e->total_pages;
+    if (free_pages) *free_pages = (int32_t)e->free_pages.size();
+    if (max_pages_per_seq) *max_pages_per_seq = e->max_pages;
+    return MTTS_OK;
+}
+
+int32_t mtts_read_page_table(MttsEngine* e, int32_t* host_table, int32_t* host_n_pages) {
+    if (!e || !host_table || !host_n_pages) return fail(MTTS_EINVAL, "null argument");
+    memcpy(host_table, e->h_page_table.data(), e->h_page_table.size() * 4);
+    memcpy(host_n_pages, e->n_pages.data(), e->n_pages.size() * 4);
+    return MTTS_OK;
+}
+
+int32_t mtts_set_forced_mode(MttsEngine* e, int32_t as_draw) {
+    if (!e) return fail(MTTS_EINVAL, "null engine");
+    e->forced_draw = as_draw ? 1 : 0;
     return MTTS_OK;
 }
 

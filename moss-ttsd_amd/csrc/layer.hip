@@ -288,3 +288,12 @@ __global__ void fill_random_bf16_kernel(uint16_t* __restrict__ p, size_t n, uint
 void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st) {
     hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, st, (uint16_t*)p, n, seed);
 }
+
+// Page-table edits handed over as launch arguments (engine.hip: pool_flush).
+struct PageEdits { int32_t n; int32_t idx[31]; int32_t val[31]; };
+__global__ void set_pages_kernel(int32_t* __restrict__ table, PageEdits ed) {
+    if ((int)threadIdx.x < ed.n) table[ed.idx[threadIdx.x]] = ed.val[threadIdx.x];
+}
+void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st) {
+    hipLaunchKernelGGL(set_pages_kernel, dim3(1), dim3(64), 0, st, table, ed);
+}

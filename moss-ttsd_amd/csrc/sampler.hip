@@ -37,7 +37,9 @@ struct LoopState {          // one per engine, device resident
     int32_t B;
     int32_t error;          // sticky device-side error
     int32_t gen_cap;        // rows of generated-token storage per slot
-    int32_t pad0, pad1;
+    int32_t forced_draw;    // forced replay: 1 = the forced row replaces the step's raw draw BEFORE the state machine
+                            //    (replay of a sampled reference run); 0 = it replaces the state machine's output
+    int32_t pad1;
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -506,6 +508,16 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
             int tok[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) tok[c] = s.unfinished ? decisions[b * 8 + c] : 0;
+            const size_t slot = ((size_t)b * cap + step) * 8;
+            const bool as_draw = forced && ls->forced_draw;
+            if (as_draw) {          // the log keeps the raw draws; the reference's history drives the state machine
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    dec_log[slot + c] = tok[c];
+                    const int f = forced[slot + c];
+                    if (f >= 0 && s.unfinished) tok[c] = f;
+                }
+            }
             // :140-141
             const bool speech = tok[0] >= sp_lo && tok[0] < sp_hi;
             if (s.unfinished && !speech && s.nas < 0) s.nas = 7;
@@ -528,12 +540,11 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
 #pragma unroll
                 for (int c = 1; c < 8; ++c) tok[c] = spad;
             }
-            const size_t slot = ((size_t)b * cap + step) * 8;
-            if (dec_log) {
+            if (dec_log && !as_draw) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) dec_log[slot + c] = tok[c];
             }
-            if (forced) {
+            if (forced && !as_draw) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     int f = forced[slot + c];

@@ -102,7 +102,7 @@ def _load_safetensors_dir(path):
 
 
 class AsteroidTTSInstruct:
-    MAX_ENGINE_BATCH = 32
+    MAX_ENGINE_BATCH = 128          # rows one engine pass carries (4 activation tiles share each weight stream)
 
     def __init__(self, config: AsteroidTTSConfig, state_dict=None, generation_config=None):
         self.config = config
@@ -113,7 +113,8 @@ class AsteroidTTSInstruct:
         self._engine_key = None
         self.device = torch.device("cpu")
         self.training = False
-        self.sample_seed = 0
+        self.sample_seed = None         # explicit Philox key for the next generate() (tests); None = from torch's seed
+        self._calls = 0
 
     # ---- loading -----------------------------------------------------------------
     @classmethod
@@ -147,11 +148,14 @@ class AsteroidTTSInstruct:
         if self.device.type != "cuda":
             raise RuntimeError("AsteroidTTSInstruct on MI355X needs model.to('cuda'): the HIP engine has no CPU path")
         cap_len = max(4096, int(need_len)) + 64
-        key = (str(self.device), cap_len)
+        slots = 32 if batch <= 32 else (64 if batch <= 64 else self.MAX_ENGINE_BATCH)
+        if self._engine is not None and self._engine_key[:2] == (str(self.device), cap_len) and self._engine_key[2] >= slots:
+            return self._engine
+        key = (str(self.device), cap_len, slots)
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = Engine(self.config.to_dict(), max_batch=self.MAX_ENGINE_BATCH, max_seq_len=cap_len,
+            self._engine = Engine(self.config.to_dict(), max_batch=slots, max_seq_len=cap_len,
                                   device=str(self.device))
             self._engine.bind_state_dict(self._sd)
             self._engine_key = key
@@ -171,19 +175,46 @@ class AsteroidTTSInstruct:
         if max_length is None:
             max_length = (T + mnt) if mnt is not None else gc.max_length
         layers, do_samples = gc.channel_settings(C)
-        seed = seed if seed is not None else (gc.seed if gc.seed is not None else self.sample_seed)
+        seed = self._next_seed(seed)
         ids = input_ids.detach().cpu().numpy()
         msk = attention_mask.detach().cpu().numpy()
-        eng = self._get_engine(B, int(max_length))
-        outs = []
-        for s in range(0, B, self.MAX_ENGINE_BATCH):
-            outs.append(eng.generate(ids[s:s + self.MAX_ENGINE_BATCH], msk[s:s + self.MAX_ENGINE_BATCH], int(max_length),
-                                     layers=layers, do_samples=do_samples, seed=int(seed) + s))
-        G = max(o.shape[1] for o in outs)
-        full = np.full((B, G, C), self.config.speech_pad_token, dtype=np.int64)
+        eng = self._get_engine(B, int(max_length) + 7)
+        if B <= self.MAX_ENGINE_BATCH:
+            # one static batch, the reference's semantics: finished rows emit (eos, 1024 x 7) until the batch ends
+            out = eng.generate(ids, msk, int(max_length), layers=layers, do_samples=do_samples, seed=seed)
+        else:
+            out = self._generate_scheduled(eng, ids, msk, int(max_length), layers, do_samples, seed)
+        return torch.from_numpy(out).to(input_ids.device)
+
+    def _next_seed(self, seed):
+        """Philox key of this call.  Explicit `seed=` / `generation_config.seed` / `model.sample_seed` win; otherwise it
+        follows torch's global seed, which is what the reference's `inference.py --seed` sets through
+        accelerate.set_seed (inference.py:69-72), advanced per call so that successive batches differ."""
+        gc = self.generation_config
+        if seed is None:
+            seed = gc.seed if gc.seed is not None else self.sample_seed
+        if seed is None:
+            seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
+        self._calls += 1
+        return int(seed)
+
+    def _generate_scheduled(self, eng, ids, msk, max_length, layers, do_samples, seed):
+        """More rows than one pass carries: the continuous batcher serves them through MAX_ENGINE_BATCH slots (a
+        finished dialogue's slot and KV pages go to the next one).  Row i draws from the Philox key seed + i."""
+        from mtts.scheduler import ContinuousBatcher
+        B, T, C = ids.shape
+        base = T - 7
+        pads = [int(np.argmax(msk[b, :base] > 0)) for b in range(B)]
+        prompts = [ids[b, pads[b]:] for b in range(B)]
+        new = max_length - T
+        cb = ContinuousBatcher(eng, slots=self.MAX_ENGINE_BATCH, gen_cap=max_length - base + 8, layers=layers,
+                               do_samples=do_samples)
+        res = cb.run(prompts, new, base_seed=seed)
+        G = max(r.shape[0] - (T - pads[b] - 7) for b, r in enumerate(res))
+        full = np.full((B, base + G, C), self.config.speech_pad_token, dtype=np.int64)
         full[:, :, 0] = self.config.eos_token_id            # finished-row padding (modeling_asteroid.py:155-158)
-        r = 0
-        for o in outs:
-            full[r:r + o.shape[0], :o.shape[1]] = o
-            r += o.shape[0]
-        return torch.from_numpy(full).to(input_ids.device)
+        for b, r in enumerate(res):
+            full[b, :base] = ids[b, :base]
+            gen = r[T - pads[b] - 7:]
+            full[b, base:base + gen.shape[0]] = gen
+        return full

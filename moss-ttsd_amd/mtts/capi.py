@@ -14,7 +14,7 @@ class MttsConfig(C.Structure):
         "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
         "num_key_value_heads", "head_dim", "channels", "speech_vocab_size", "speech_pad_token",
         "speech_range_lo", "speech_range_hi", "eos_token_id", "max_position")] + [
-        ("rms_norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_seq_len", C.c_int32)]
+        ("rms_norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_seq_len", C.c_int32), ("kv_pool_pages", C.c_int32)]
 
 
 class MttsSamplerCfg(C.Structure):
@@ -33,7 +33,12 @@ class MttsCodecConfig(C.Structure):
 
 
 class MttsError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
+
+
+ENOMEM = -3
 
 
 _lib = None
@@ -60,6 +65,10 @@ _SIGS = {
     "mtts_slot_states": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_slot_read": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mtts_read_seq_state": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_slot_evict": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mtts_kv_pool_state": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mtts_read_page_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_set_forced_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mtts_export_codes": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mtts_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mtts_profile_read": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -106,4 +115,4 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise MttsError(f"libmtts error {rc}: {lib().mtts_last_error().decode()}")
+        raise MttsError(f"libmtts error {rc}: {lib().mtts_last_error().decode()}", rc)

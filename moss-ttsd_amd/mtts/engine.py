@@ -39,7 +39,7 @@ def rope_tables(head_dim, theta, rows, device):
 
 
 class Engine:
-    def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0"):
+    def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0", kv_pool_pages: int = 0):
         if not torch.cuda.is_available():
             raise capi.MttsError("no GPU visible: the mtts engine only runs on MI355X (no CPU fallback)")
         self.cfg = cfg
@@ -51,9 +51,10 @@ class Engine:
                   "eos_token_id"):
             setattr(c, k, int(cfg[k]))
         c.speech_range_lo, c.speech_range_hi = int(cfg["speech_token_range"][0]), int(cfg["speech_token_range"][1])
-        c.max_position = int(max_seq_len) + 8
+        c.max_position = int(max_seq_len) + 16
         c.rms_norm_eps = float(cfg["rms_norm_eps"])
         c.max_batch, c.max_seq_len = int(max_batch), int(max_seq_len)
+        c.kv_pool_pages = int(kv_pool_pages)          # 0: every slot can reach max_seq_len at once
         self._h = C.c_void_p()
         capi.check(self.lib.mtts_engine_create(C.byref(c), self.device.index or 0, C.byref(self._h)))
         cos, sin = rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position, self.device)
@@ -97,10 +98,15 @@ class Engine:
         assert ids.ndim == 3 and ids.shape[2] == 8 and m.shape == ids.shape[:2]
         return ids, m
 
-    def generate(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0, forced=None):
+    def generate(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0, forced=None,
+                 forced_as_draw=False):
+        """forced (verification hook): int64 [B,G,8] full sequences of a reference run.  -> (ids, decisions [steps,B,8]).
+        forced_as_draw: the forced row replaces each step's raw draw before the state machine (replay of a SAMPLED
+        run); decisions are then the raw draws."""
         ids, m = self._host_inputs(input_ids, attention_mask)
         B, T, _ = ids.shape
-        cap = int(max_length)
+        cap = int(max_length) + 7          # a flush that starts within 7 steps of max_length runs to its end
+        capi.check(self.lib.mtts_set_forced_mode(self._h, 1 if (forced is not None and forced_as_draw) else 0))
         out = np.zeros((B, cap, 8), dtype=np.int64)
         out_len = C.c_int32(0)
         scfg = sampler_cfgs(layers, do_samples)
@@ -172,6 +178,24 @@ class Engine:
         n = C.c_int32(0)
         capi.check(self.lib.mtts_slot_read(self._h, int(slot), buf.ctypes.data, int(capacity), C.byref(n)))
         return buf[:n.value].copy()
+
+    def evict(self, slot):
+        """Scheduler mode: drop the dialogue in `slot` and return its KV pages (it is re-submitted later)."""
+        capi.check(self.lib.mtts_slot_evict(self._h, int(slot), None))
+
+    def kv_pool_state(self):
+        """-> (pages in the pool, pages free, pages per page-table row)."""
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.mtts_kv_pool_state(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def page_table(self, max_batch):
+        """-> (int32 [max_batch, pages per row] page table as the host tracks it, int32 [max_batch] pages owned)."""
+        _, _, mp = self.kv_pool_state()
+        t = np.zeros((int(max_batch), mp), dtype=np.int32)
+        n = np.zeros(int(max_batch), dtype=np.int32)
+        capi.check(self.lib.mtts_read_page_table(self._h, t.ctypes.data, n.ctypes.data))
+        return t, n
 
     def seq_state(self):
         """-> (needs_additional_steps[B], unfinished[B], kv_len[B]) numpy int32."""

@@ -338,11 +338,16 @@ if __name__ == "__main__":
                     hi, 301, 1, 20, 0.4, 24, dict(ragged=False)),
         # fp32 run of the first case: tight-tolerance pin of the oracle's structure
         "ar_text_ragged_fp32": ({}, lo, 103, 3, 24, 0.0, 40, dict(dtype=torch.float32)),
+        # stop rule: row 1's non-speech pick at step 25 falls 1 step before max_length (17 + 27): its delay-pattern
+        # flush runs 6 steps PAST max_length while rows 0/2 get finished-row padding (modeling_asteroid.py:165-168)
+        "ar_flush_past_max": ({}, lo, 103, 3, 24, 0.0, 20, {}),
         # processors on the greedy path (repetition penalty changes the argmax)
         "ar_rep_penalty": ({}, hi, 404, 2, 24, 0.3, 24, dict(layers=[dict(repetition_penalty=1.3)] * 8)),
     }
     if "all" in which or "ar" in which:
         for name, (co, wkw, seed, b, pl, af, mn, kw) in AR_CASES.items():
+            if len(which) > 1 and "all" not in which and name not in which and any(w.startswith("ar_") for w in which):
+                continue                                   # `make_golden.py ar ar_flush_past_max`: only the named cases
             make_case(name, co, wkw, seed, b, pl, af, mn, **kw)
     if "all" in which or "pin" in which:
         # The reference's OWN CustomMixin._sample (under RefModelSample's 4.53.2 helper shims) against the restated

@@ -13,7 +13,7 @@ torch = pytest.importorskip("torch")
 from mtts import capi, synth  # noqa: E402
 from oracle import asteroid_oracle as ao  # noqa: E402
 
-CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty"]
+CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty", "ar_flush_past_max"]
 MARGIN_OK = 0.02
 
 

@@ -1,0 +1,217 @@
+"""Parity at the contexts BASELINE.json's configs name (2 k, 4 k, 8 k tokens), the paged-KV indirection with
+arbitrary page tables, the KV page pool under over-subscription, and a full-size batch at the bench's own operating
+point.  HIP engine through the C ABI vs the numpy oracle.  -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from mtts import capi, synth  # noqa: E402
+from oracle import asteroid_oracle as ao  # noqa: E402
+
+MARGIN_OK = 0.02
+_ORACLE_RUNS = {}
+
+
+def _long_prompts(cfg, seed, lens, audio_frac=0.3):
+    """Ragged batch of delay-shifted prompts with the given lengths (slots, incl. the 7-slot delayed tail),
+    left-padded to the longest (what generation_utils.rpadding builds, generation_utils.py:221-237)."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for t in lens:
+        n = t - 7
+        n_audio = int(n * audio_frac)
+        n_text = n - n_audio
+        raw = np.full((n, 8), 1024, dtype=np.int64)
+        raw[:n_text, 0] = rng.integers(0, 151643, n_text)
+        if n_audio:
+            raw[n_text:, 0] = 151665 + rng.integers(0, 1024, n_audio)
+            raw[n_text:, 1:] = rng.integers(0, 1024, (n_audio, 7))
+        seqs.append(synth.shifting_inputs(raw, cfg["pad_token_id"]))
+    return synth.left_pad(seqs, cfg["pad_token_id"])
+
+
+@pytest.mark.parametrize("ctx,fuse", [(2100, "1000000"), (2100, "0"), (4200, "1000000"), (4200, "0"),
+                                      (8300, "1000000"), (8300, "0")])
+def test_long_context_decode_vs_oracle(monkeypatch, ctx, fuse):
+    """B=2 ragged prompts of ~ctx tokens (tiny dims), then 70 greedy decode steps across a page boundary: the
+    oracle's run replayed through the engine.  ctx 8300 = 130 KV pages: the softmax statistics loop of attn_pv
+    walks the per-page pairs in three strides and attn_combine sums 17 pass-B chunks; prefill runs 5 passes of 2048
+    rows through the tile-sharing MFMA attention.  `fuse` selects the decode q/k/v epilogue inside the attention
+    kernels ("1000000") or as its own launch ("0": what a full-size batch at 4 k runs)."""
+    from mtts.engine import Engine
+    monkeypatch.setenv("MTTS_FUSE_QKV_MAX", fuse)
+    cfg = synth.tiny(max_position_embeddings=16384)
+    w = synth.synth_weights(cfg, 141, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = _long_prompts(cfg, 142, [ctx, ctx - 37 - ctx // 9])
+    T = ids.shape[1]
+    steps = 70
+    max_length = T + steps
+    if ctx not in _ORACLE_RUNS:                                # the two `fuse` settings share one oracle run
+        orc = ao.AsteroidOracle(cfg, w, "bf16")
+        orc.prefill_chunk = 512
+        gold, logs = orc.generate(ids, mask, max_length, return_logits=True)
+        _ORACLE_RUNS.clear()
+        _ORACLE_RUNS[ctx] = (gold, np.stack(orc.last_margins), [logs[0]])
+    gold, margins, logs = _ORACLE_RUNS[ctx]
+    assert gold.shape[1] - (T - 7) >= steps                   # nobody flushed early
+    eng = Engine(cfg, max_batch=2, max_seq_len=ctx + 128)
+    eng.bind_state_dict(w)
+    # logits straight after the prompt pass
+    eng.begin(ids, mask, max_length)
+    l0, l17 = eng.read_logits()
+    exact = total = 0
+    for c in range(8):
+        got = l0 if c == 0 else l17[c - 1]
+        ref = logs[0][c]
+        fin = np.isfinite(ref)
+        tol = (2.0 ** -6) * np.abs(np.where(fin, ref, 0)).max(axis=-1, keepdims=True)
+        assert (np.abs(np.where(fin, got - np.where(fin, ref, 0), 0)) <= tol).all(), c
+        exact += int((got[fin] == ref[fin]).sum())
+        total += int(fin.sum())
+    assert exact >= 0.3 * total, (exact, total)
+    # teacher-forced replay of the oracle's run
+    out, dec = eng.generate(ids, mask, max_length, forced=gold)
+    eng.close()
+    want = gold[:, T - 7:].transpose(1, 0, 2)
+    assert dec.shape == want.shape
+    free = np.ones_like(margins, dtype=bool)
+    for s in range(7):
+        free[s, :, s + 1:] = False
+    safe = free & (margins >= MARGIN_OK)
+    assert safe.sum() > 0.8 * free.sum()
+    bad = np.argwhere(safe & (dec != want))
+    assert len(bad) == 0, bad[:10]
+    assert np.array_equal(dec[~free], want[~free])
+    assert (dec[free] == want[free]).mean() > 0.97
+
+
+def test_shuffled_page_table_gives_identical_tokens(monkeypatch):
+    """The attention kernels reach every K/V page through the page table (attn.hip: page_table[seq][pg]).  With
+    MTTS_PAGE_SHUFFLE the pool hands pages out in a random order, so the table is an arbitrary permutation instead of
+    consecutive numbers: prompts of 150..330 tokens (6 pages), 200 decode steps across three page boundaries, greedy
+    and sampled, must give exactly the tokens of the in-order run."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 151, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = _long_prompts(cfg, 152, [330, 150, 257])
+    max_length = ids.shape[1] + 200
+    layers = [dict(top_k=40, top_p=0.9, temperature=1.1, repetition_penalty=1.05)] * 8
+    outs, tables = [], []
+    for shuffle in (None, "7", "12345"):
+        if shuffle is None:
+            monkeypatch.delenv("MTTS_PAGE_SHUFFLE", raising=False)
+        else:
+            monkeypatch.setenv("MTTS_PAGE_SHUFFLE", shuffle)
+        eng = Engine(cfg, max_batch=4, max_seq_len=640)
+        eng.bind_state_dict(w)
+        g = eng.generate(ids, mask, max_length)
+        t, n = eng.page_table(4)
+        tables.append([t[b, :n[b]].tolist() for b in range(3)])
+        s = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=9)
+        outs.append((g, s))
+        eng.close()
+    assert outs[0][0].shape[1] - (ids.shape[1] - 7) >= 200
+    for k in (1, 2):
+        assert np.array_equal(outs[0][0], outs[k][0]) and np.array_equal(outs[0][1], outs[k][1])
+        flat = [p for row in tables[k] for p in row]
+        assert len(set(flat)) == len(flat)                                  # no page owned twice
+        assert any(row != sorted(row) or (row and row[-1] - row[0] != len(row) - 1) for row in tables[k])
+    assert tables[1] != tables[2]
+
+
+def test_kv_page_pool_oversubscribed_equals_standalone():
+    """A pool of 30 pages (1 920 tokens) behind 6 slots whose dialogues may each reach 640 tokens (6 x 11 = 66 pages if
+    every slot were given its worst case up front): 16 dialogues of 30..260 prompt tokens and up to 260 new tokens run
+    to completion through the continuous batcher -- pages are taken as dialogues grow, returned when they finish, and
+    when the pool runs dry the youngest dialogue is evicted and re-run.  Every dialogue's tokens equal its batch-1
+    run with the same seed (greedy and sampled); afterwards every page is back in the pool."""
+    from mtts.engine import Engine
+    from mtts.scheduler import ContinuousBatcher
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 161, emb_row_sigma=0.6, speech_boost=5.0, eos_boost=3.0)
+    eng = Engine(cfg, max_batch=6, max_seq_len=640, kv_pool_pages=30)
+    eng.bind_state_dict(w)
+    solo = Engine(cfg, max_batch=1, max_seq_len=640)
+    solo.bind_state_dict(w)
+    rng = np.random.default_rng(5)
+    prompts, mnts = [], []
+    for i in range(16):
+        n = int(rng.integers(30, 260))
+        raw = np.full((n, 8), 1024, dtype=np.int64)
+        raw[:, 0] = rng.integers(0, 151643, n)
+        k = int(rng.integers(0, n // 2 + 1))
+        if k:
+            raw[n - k:, 0] = 151665 + rng.integers(0, 1024, k)
+            raw[n - k:, 1:] = rng.integers(0, 1024, (k, 7))
+        prompts.append(synth.shifting_inputs(raw, cfg["pad_token_id"]))
+        mnts.append(int(rng.integers(40, 260)))
+    total, free0, per_seq = eng.kv_pool_state()
+    assert (total, free0, per_seq) == (30, 30, 11)
+    worst = sum((p.shape[0] - 7 + m + 7 + 63) // 64 for p, m in zip(prompts, mnts))
+    assert worst > 3 * total                                   # far more than the pool if reserved up front
+    for layers, ds in ((None, None), ([dict(top_k=20, top_p=0.9, temperature=1.1, repetition_penalty=1.2)] * 8, [True] * 8)):
+        cb = ContinuousBatcher(eng, slots=6, gen_cap=280, layers=layers, do_samples=ds, steps_per_poll=8)
+        seeds = list(range(300, 316))
+        got = cb.run(prompts, mnts, seeds=seeds)
+        for i, p in enumerate(prompts):
+            alone = solo.generate(p[None], np.ones((1, p.shape[0])), p.shape[0] + mnts[i], layers=layers, do_samples=ds,
+                                  seed=seeds[i])[0]
+            assert got[i].shape == alone.shape, (i, got[i].shape, alone.shape)
+            assert np.array_equal(got[i], alone), i
+        assert eng.kv_pool_state()[1] == total                 # every page returned
+        print("kv pool run: evictions", cb.evictions, "engine steps", cb.engine_steps)
+    eng.close()
+    solo.close()
+
+
+def _rand_weights_on_gpu(cfg, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    lo, hi = cfg["speech_token_range"]
+    for name, shape, kind in synth.weight_shapes(cfg):
+        if kind == "norm":
+            t = (1.0 + 0.1 * torch.randn(shape, device="cuda", generator=g)).to(torch.bfloat16)
+        else:
+            t = (0.02 * torch.randn(shape, device="cuda", generator=g)).to(torch.bfloat16)
+            if name.endswith("embedding_list.0.weight"):
+                t[lo:hi] *= 8.0
+        yield name, t
+
+
+def test_full_size_batch32_at_4k_context_invariance():
+    """BASELINE configs[2] at size: ASSUMED 1.7B dims (28 layers), 32 dialogues with ragged ~4 k-token prompts
+    (prefill: 2048-row passes, 64 KV pages per dialogue), then 48 decode steps at a 4 k context -- the operating
+    point bench.py times (rows x pages = 2048: the q/k/v epilogue runs as its own launch).  Size-independent
+    properties: (1) a dialogue's tokens do not depend on which dialogues share its batch or on its row -- the 4-row
+    subset runs with rows x pages = 256, i.e. through the FUSED q/k/v epilogue and other grids, and must still give
+    identical tokens, greedy and sampled with per-row Philox streams aside; (2) the first 7 steps copy the delayed
+    prompt tail; (3) the run is reproducible."""
+    from mtts.engine import Engine
+    cfg = synth.assumed_1p7b()
+    eng = Engine(cfg, max_batch=32, max_seq_len=4096 + 128)
+    for name, t in _rand_weights_on_gpu(cfg, 5):
+        eng.bind(name, t)
+    rng = np.random.default_rng(17)
+    lens = [4060] + [int(x) for x in rng.integers(3700, 4050, 31)]
+    ids, mask = _long_prompts(cfg, 19, lens, audio_frac=0.5)
+    T = ids.shape[1]
+    max_length = T + 48
+    full = eng.generate(ids, mask, max_length)                 # greedy
+    assert full.shape[1] >= T - 7 + 48
+    rows = [0, 7, 19, 31]
+    sub = eng.generate(ids[rows], mask[rows], max_length)
+    n = min(sub.shape[1], full.shape[1])
+    assert np.array_equal(sub[:, :n], full[rows][:, :n])
+    again = eng.generate(ids, mask, max_length)
+    assert np.array_equal(again, full)
+    for s in range(7):
+        assert np.array_equal(full[:, T - 7 + s, s + 1:], ids[:, T - 7 + s, s + 1:])
+    kv = eng.seq_state()[2]
+    assert kv.max() >= 4096                                    # the run did reach a 4 k context
+    eng.close()

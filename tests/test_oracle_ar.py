@@ -12,7 +12,7 @@ import pytest
 from mtts import synth
 from oracle import asteroid_oracle as ao
 
-CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty"]
+CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty", "ar_flush_past_max"]
 MARGIN_OK = 0.02  # decisions whose top-2 relative gap in the reference exceeds ~5 bf16 ulps
 
 
