@@ -52,6 +52,12 @@ class XY_Tokenizer:
         return {"syn_wav_list": self._get_engine().decode(codes_list, overlap_seconds=overlap_seconds)}
 
     @torch.inference_mode()
+    def decode_each(self, codes_list, overlap_seconds=10, device=None):
+        """Like one `decode([codes])` call per sequence (what the reference's process_batch does), executed together:
+        windows of equal length from all sequences share codec calls (mtts/codec.py: CodecEngine.decode_each)."""
+        return {"syn_wav_list": self._get_engine().decode_each(codes_list, overlap_seconds=overlap_seconds)}
+
+    @torch.inference_mode()
     def encode(self, wav_list, overlap_seconds=10, device=None):
         """B x FloatTensor(T,) at 16 kHz -> {"codes_list": B x LongTensor(nq, T//1280)}  (reference model.py:131-192)."""
         return {"codes_list": self._get_engine().encode(wav_list, overlap_seconds=overlap_seconds)}

@@ -170,7 +170,7 @@ struct MttsEngine {
 static hipStream_t S(void* s) { return (hipStream_t)s; }
 
 const char* mtts_last_error(void) { return g_err; }
-int32_t mtts_version(void) { return 100; }
+int32_t mtts_version(void) { return 200; }
 
 template <typename T>
 static int dalloc(T** p, size_t n, bool zero = true) {

@@ -3,8 +3,8 @@ delay-pattern helpers) with the model and the codec replaced by the MI355X engin
 
 Behaviour follows /root/reference/generation_utils.py: item parsing :27-87, prompt layout
 :180-208, delay shift :211-218, left padding :221-237, un-shift :416-425, valid-length search
-:240-249 (channel 1), text normalisation :252-338, per-sample codec decode and the
-None-on-failure convention :434-467.  torchaudio is not required: wav I/O uses the stdlib.
+:240-249 (channel 1), text normalisation :252-338, the None-on-failure convention :434-467 (the codec
+decodes the windows of all samples together; the reference calls it once per sample).  torchaudio is not required: wav I/O uses the stdlib.
 """
 from __future__ import annotations
 
@@ -67,19 +67,56 @@ def process_jsonl_item(item):
 
 # ---- audio loading (prompt audio; stdlib wav reader, linear-phase windowed-sinc resampler) --------
 def _read_wav(path):
-    with wave.open(path, "rb") as w:
-        n, ch, sw, sr = w.getnframes(), w.getnchannels(), w.getsampwidth(), w.getframerate()
-        raw = w.readframes(n)
-    if sw != 2:
-        raise ValueError(f"{path}: only PCM16 wav is supported")
-    x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    return torch.from_numpy(x.reshape(-1, ch).T.copy()), sr
+    """RIFF/WAVE reader standing in for torchaudio.load (reference generation_utils.py:96): -> (float32 [channels, n]
+    in [-1, 1), sample_rate).  PCM 8/16/24/32-bit and IEEE float32, plain or WAVE_FORMAT_EXTENSIBLE.  The `data`
+    chunk is read by its own size (clipped to the file), not by the RIFF header's: some of the reference's example
+    files carry a RIFF size a few bytes short of the file, which the stdlib `wave` module would truncate by."""
+    import struct
+    with open(path, "rb") as f:
+        d = f.read()
+    if len(d) < 12 or d[:4] != b"RIFF" or d[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    fmt = data = None
+    i = 12
+    while i + 8 <= len(d):
+        cid, sz = d[i:i + 4], struct.unpack("<I", d[i + 4:i + 8])[0]
+        body = d[i + 8:i + 8 + sz]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            data = body
+            break
+        i += 8 + sz + (sz & 1)
+    if fmt is None or data is None or len(fmt) < 16:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    frame = ch * (bits // 8)
+    if ch < 1 or frame == 0:
+        raise ValueError(f"{path}: bad fmt chunk")
+    data = data[:len(data) // frame * frame]
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(data, dtype="<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 8:
+        x = (np.frombuffer(data, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and bits == 24:
+        b3 = np.frombuffer(data, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b3[:, 0] | (b3[:, 1] << 8) | (b3[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif tag == 1 and bits == 32:
+        x = (np.frombuffer(data, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(data, dtype="<f4").astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported wav encoding (format tag {tag}, {bits} bits)")
+    return torch.from_numpy(x.reshape(-1, ch).T.copy()), int(sr)
 
 
 def _resample(wav, sr, target, width=6, rolloff=0.99):
     """Windowed-sinc polyphase resampling with torchaudio.functional.resample's published defaults
     (sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99).  torchaudio is absent here, so this
-    path is parity-unpinned; it only feeds the (not yet built) prompt encoder."""
+    path is PARITY UNPINNED (tests/test_io_cpu.py checks its length rule and gain); it feeds the prompt encoder."""
     import math
     g = math.gcd(int(sr), int(target))
     o, n = int(sr) // g, int(target) // g
@@ -247,24 +284,41 @@ def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, sta
             speech_ids[..., j] = outputs[:, j:seq_len + j, j]
         speech_ids[..., 0] -= SPEECH_OFFSET
         last = find_max_valid_positions(speech_ids)
-        results = []
+        results = [None] * n
+        valid = []
         for i in range(n):
+            if int(last[i]) + 1 <= 0:
+                print(f"Sample {start_idx + i} has no valid speech tokens")
+            else:
+                valid.append(i)
+                print(f"Speech token shape for sample {start_idx + i}: {speech_ids[i, :int(last[i]) + 1].shape}")
+
+        def pack(i, wav):
+            wav = wav.cpu().detach()
+            return {"audio_data": wav.unsqueeze(0) if wav.ndim == 1 else wav,
+                    "sample_rate": spt.output_sample_rate, "index": start_idx + i}
+
+        # The reference decodes one sample per spt.decode call (generation_utils.py:434-450).  Here the 30 s windows
+        # of ALL samples go through the codec together, each exactly as in its own call (`decode_each`: only windows
+        # of equal length share a call, nothing is padded); if that batched call fails, fall back to one call per
+        # sample so that a bad sample still only costs its own entry (None).
+        wavs = None
+        if valid and hasattr(spt, "decode_each"):
             try:
-                end = int(last[i]) + 1
-                if end <= 0:
-                    print(f"Sample {start_idx + i} has no valid speech tokens")
-                    results.append(None)
-                    continue
-                codes = speech_ids[i, :end].permute(1, 0)
-                print(f"Speech token shape for sample {start_idx + i}: {speech_ids[i, :end].shape}")
-                wav = spt.decode([codes], overlap_seconds=10)["syn_wav_list"][0].cpu().detach()
-                results.append({"audio_data": wav.unsqueeze(0) if wav.ndim == 1 else wav,
-                                "sample_rate": spt.output_sample_rate, "index": start_idx + i})
+                wavs = spt.decode_each([speech_ids[i, :int(last[i]) + 1].permute(1, 0) for i in valid],
+                                       overlap_seconds=10)["syn_wav_list"]
+            except Exception as e:
+                print(f"Batched codec decode failed ({str(e)}); decoding sample by sample...")
+        for k, i in enumerate(valid):
+            try:
+                wav = wavs[k] if wavs is not None else \
+                    spt.decode([speech_ids[i, :int(last[i]) + 1].permute(1, 0)], overlap_seconds=10)["syn_wav_list"][0]
+                results[i] = pack(i, wav)
                 print(f"Audio generation completed: sample {start_idx + i}")
             except Exception as e:
                 print(f"Error processing sample {start_idx + i}: {str(e)}, skipping...")
                 traceback.print_exc()
-                results.append(None)
+                results[i] = None
         return meta, results
     except Exception as e:
         print(f"Error during batch processing: {str(e)}")

@@ -334,3 +334,35 @@ class CodecEngine:
             return [torch.zeros(0, device=self.device) for _ in range(B)]
         full = torch.cat(wavs, dim=-1)
         return [full[i, :lens[i] * up] for i in range(B)]
+
+    def decode_each(self, codes_list, overlap_seconds=10, windows_per_call=32):
+        """Every sequence decoded as if it were alone in its call -- what the reference's process_batch does, one
+        `spt.decode([codes])` per sample (generation_utils.py:434-450) -- but executed together: the 30 s windows of
+        ALL sequences are flattened and run `windows_per_call` at a time.  `decode()` above keeps XY_Tokenizer.decode's
+        batch semantics, where short sequences are zero-padded to the longest and the padded frames leak into a
+        sequence's last frames through the convolutions (so a sample's waveform depends on what it is batched with);
+        here only windows of EQUAL length share a call, so nothing is padded: all full windows (375 codes) go
+        together, each ragged last window with the others of its length."""
+        c = self.cfg
+        duration = 30 - overlap_seconds
+        chunk_len = int(30 * c["input_sample_rate"] // c["encoder_downsample_rate"])
+        dur_len = int(duration * c["input_sample_rate"] // c["encoder_downsample_rate"])
+        up = c["decoder_upsample_rate"]
+        dur_wav = dur_len * up
+        B = len(codes_list)
+        codes = [torch.as_tensor(x).to(device=self.device, dtype=torch.int64) for x in codes_list]
+        lens = [int(x.shape[-1]) for x in codes]
+        by_len = {}
+        for b in range(B):       # window w of a sequence of n codes covers codes [w*dur_len, min(w*dur_len + chunk_len, n))
+            for w in range((lens[b] + dur_len - 1) // dur_len):
+                by_len.setdefault(min(lens[b] - w * dur_len, chunk_len), []).append((b, w))
+        outs = [torch.zeros(lens[b] * up, dtype=torch.float32, device=self.device) for b in range(B)]
+        for cl, jobs in sorted(by_len.items(), reverse=True):
+            for g in range(0, len(jobs), int(windows_per_call)):
+                grp = jobs[g:g + int(windows_per_call)]
+                blk = torch.stack([codes[b][:, w * dur_len:w * dur_len + cl] for b, w in grp], dim=1).contiguous()
+                y = self.detokenize(blk, [cl] * len(grp))
+                k = int(min(cl * up, dur_wav))
+                for j, (b, w) in enumerate(grp):
+                    outs[b][w * dur_wav:w * dur_wav + k] = y[j, :k]
+        return outs

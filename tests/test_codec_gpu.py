@@ -128,3 +128,25 @@ def test_codec_encode_decode_roundtrip_shapes():
     out = eng.decode(codes)
     assert [o.shape[0] for o in out] == [c.shape[1] * 1920 for c in codes]
     eng.close()
+
+
+def test_codec_decode_each_equals_per_sample_calls():
+    """CodecEngine.decode_each runs the 30 s windows of ALL sequences in shared calls (what process_batch uses) while
+    keeping the reference pipeline's semantics of one `spt.decode([codes])` per sample (generation_utils.py:434-450):
+    only windows of equal length share a call.  Seven sequences of 13..760 codes (1..3 windows, ragged last windows,
+    two of equal length): identical waveforms, for two call sizes."""
+    from mtts.codec import CodecEngine
+    cfg = synth_codec.reduced(dec_layers=2, voc_layers=2)
+    w = synth_codec.synth_weights(cfg, 41)
+    eng = CodecEngine(cfg)
+    eng.bind_state_dict(w)
+    rng = np.random.default_rng(42)
+    codes = [torch.from_numpy(rng.integers(0, 1024, (8, n))) for n in (40, 375, 760, 13, 410, 760, 250)]
+    solo = [eng.decode([c])[0].cpu().numpy() for c in codes]
+    for wpc in (32, 3):
+        both = [x.cpu().numpy() for x in eng.decode_each(codes, windows_per_call=wpc)]
+        for a, b in zip(solo, both):
+            assert a.shape == b.shape
+            rms = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
+            assert rms <= 1e-6, (wpc, rms)
+    eng.close()

@@ -486,3 +486,41 @@ def test_continuous_batching_equals_standalone(engines):
         static = sum(max(mnts[j:j + 4]) + 7 for j in range(0, 11, 4))
         assert cb.engine_steps <= static + 3 * 5 * 3
     eng.close()
+
+
+def test_sampled_run_replay_against_reference_support(golden_dir):
+    """ar_sampled.npz: a SAMPLED run of the reference's real `_sample` with the processed scores (kept set) of every
+    step.  Replayed through the engine with the forced row taking the place of each raw draw (so the device state
+    machine follows the reference's history): the run must reproduce the reference's ids (state machine), and the
+    engine's own draws -- Philox, same rule as the oracle -- must fall inside the reference's kept set and equal the
+    oracle's draws for the same key (a bf16 tie on a top-k / top-p boundary may move one: <= 3 %)."""
+    z = np.load(os.path.join(golden_dir, "ar_sampled.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth.synth_weights(cfg, int(z["seed"]), **json.loads(str(z["wkw"])))
+    from mtts.engine import Engine
+    eng = Engine(cfg, max_batch=2, max_seq_len=256)
+    eng.bind_state_dict(w)
+    layers = json.loads(str(z["layers"]))
+    gold = z["out_ids"]
+    T = z["input_ids"].shape[1]
+    out, dec = eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers,
+                            do_samples=[True] * 8, seed=77, forced=gold, forced_as_draw=True)
+    eng.close()
+    assert np.array_equal(out, gold)
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    _, odec, _ = orc.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers,
+                              do_samples=[True] * 8, seed=77, forced=gold, forced_as_draw=True)
+    assert dec.shape == odec.shape
+    kept = z["kept_idx"]
+    n = inside = same = 0
+    for s in range(dec.shape[0]):
+        for b in range(dec.shape[1]):
+            if s > 0 and gold[b, T - 7 + s - 1, 0] == cfg["eos_token_id"]:
+                continue                                   # finished row: no draw
+            for c in range(8):
+                if s < 7 and c >= s + 1:
+                    continue                               # teacher-forced slot
+                n += 1
+                inside += int(dec[s, b, c] in kept[s, b, c])
+                same += int(dec[s, b, c] == odec[s, b, c])
+    assert n > 300 and inside >= 0.97 * n and same >= 0.97 * n, (n, inside, same)
