@@ -102,9 +102,10 @@ int32_t mtts_weights_ready(MttsEngine* e);   /* 0 when every tensor is bound */
  * sampler[8], seed: sampling stream (Philox4x32-10).
  * Prefills the first T-7 slots, then runs the decode loop on the device until
  * every row is finished.  out: host_out_ids int64 [B, out_capacity, 8] receives
- * [B, T-7+G, 8]; *out_len = T-7+G.  G can exceed max_length - (T-7) by up to 7: a dialogue whose EOS falls within 7 steps
- * of max_length still runs its delay-pattern flush, as the reference does (modeling_asteroid.py:165-168); size
- * out_capacity as max_length + 7.
+ * [B, T-7+G, 8]; *out_len = T-7+G.  G can exceed max_length - (T-7) by up to 14, exactly as in the reference
+ * (modeling_asteroid.py:140-141,165-168): a dialogue whose EOS falls within 7 steps of max_length still runs its
+ * delay-pattern flush, and while it does, a row that was cut off by max_length is resurrected for a flush of its own
+ * as soon as its channel-0 pick is not a speech token; size out_capacity as max_length + 14.
  * host_forced (verification hook, may be NULL): int64 [B, forced_len, 8] full
  * sequences; when given, every step's own decision is written to
  * host_decisions int64 [G,B,8] and the forced row is appended instead. */

@@ -75,3 +75,26 @@ struct RowMeta {
     int32_t last;    // 1 if logits are wanted for this row
     int32_t pad;
 };
+
+// ---- small-batch decode path (1..SMALL_RP dialogues) --------------------------------------------------------------
+// With a handful of rows the activation is a few KiB, so the work of the small kernels between two GEMMs (split-K
+// reduce + residual + RMSNorm; the sum of the P.V chunk partials) is cheap enough to be redone by every GEMM block as
+// a prologue that leaves the MFMA B operand in LDS: three launches per layer disappear (gemm.hip: gemv_small_kernel).
+#define SMALL_RP 4
+enum { PRO_NONE = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_ROWS = 3 };
+struct SmallPro {
+    int rows;                  // live rows (<= SMALL_RP); only these are stored
+    // PRO_NORM: x' = bf16(x + bf16(sum of slabs)); xn = RMSNorm(x') * w   (resid_norm_kernel's arithmetic, same order)
+    const uint16_t* x_in;      // [rows][H] residual stream
+    uint16_t* x_out;           // x' goes here (the other ping-pong buffer; written by block (0,0)); may be null
+    const float* slabs;        // [ksplit][MTTS_PFCAP][slab_npad] fp32 split-K partials of the previous Linear; ksplit 0: none
+    int ksplit, slab_npad;
+    const uint16_t* norm_w;
+    float eps;
+    // PRO_COMBINE: attention output = bf16(sum over pass-B chunks of the fp32 partials)   (attn_combine_kernel's arithmetic)
+    const float* opart;        // [(row*nq + head)][nchunks_max][128]
+    const RowMeta* meta;
+    int nchunks_max, nq, pages_per_chunk;
+    // PRO_ROWS: the activation is row-major bf16 [rows][K]
+    const uint16_t* xrows;
+};

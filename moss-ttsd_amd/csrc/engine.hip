@@ -29,6 +29,10 @@ void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void*
 int mtts_tile_ksplit(int Npad, int K, int R);
 void launch_gemm_tile(int epi, int R, int ksplit, const void* Wp, const void* Xp, int K, int Npad, int n_valid,
                       float* partial, uint16_t* out, hipStream_t st);
+int mtts_small_lds_bytes(const GemmPlan& p, int K, int pro);
+enum { EPI_SILU_RM = 3 };
+void launch_gemv_small(int epi, int pro, const GemmPlan& p, const void* Wp, int K, int Npad, int n_valid, float* partial,
+                       uint16_t* out, const SmallPro& pr, hipStream_t st);
 void launch_pack_weight(const void* src, void* dst, int rows, int cols, int rows_pad, int row_mul, int row_off, hipStream_t st);
 void launch_pack_rows(const void* src, void* dst, int R, int K, int tiles, hipStream_t st);
 void launch_reduce_partial_bf16(const float* partial, void* out, int ksplit, int Npad, int n_valid, int R, hipStream_t st);
@@ -70,6 +74,7 @@ void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, i
 struct PageEdits { int32_t n; int32_t idx[31]; int32_t val[31]; };     // page-table entries handed over as launch arguments
 void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st);
 #define FLUSH_STEPS 7          // a dialogue whose EOS falls within 7 steps of max_length still runs its delay-pattern flush (modeling_asteroid.py:165-168)
+#define LINGER_STEPS 14        // static batch: a row finished BY max_length can be resurrected for a flush while another row's flush is still running (sampler.hip: update_kernel), so a batch may run up to 6 + 8 steps past max_length
 
 // ---- errors -------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -113,6 +118,9 @@ struct MttsEngine {
     GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17;
     // workspaces
     float* partial = nullptr;
+    float* partial2 = nullptr;          // small-batch path: o_proj / down_proj slabs (the qkv slabs stay in `partial`)
+    void *x2 = nullptr, *act_rm = nullptr;   // small-batch path: second residual buffer (ping-pong), row-major SwiGLU output
+    int small_rows = SMALL_RP;          // decode batches up to this many dialogues take the small-batch path (0 = off)
     void *x = nullptr, *xn = nullptr, *attn_p = nullptr, *act_p = nullptr, *qbuf = nullptr, *hlast = nullptr, *xh = nullptr;
     void *logits0 = nullptr, *logits17 = nullptr, *join_logits0 = nullptr, *join_logits17 = nullptr;
     void* scores = nullptr;
@@ -273,6 +281,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
     if (const char* g = getenv("MTTS_FUSE_QKV_MAX")) e->fuse_qkv_max = atoi(g);
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
+    if (const char* g = getenv("MTTS_SMALL_ROWS")) e->small_rows = std::min(std::max(atoi(g), 0), SMALL_RP);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
     e->nq = c->num_attention_heads; e->nkv = c->num_key_value_heads;
     e->V0 = c->vocab_size; e->Vs = c->speech_vocab_size;
@@ -308,6 +317,9 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     // activations hold a whole prefill pass (MTTS_PFCAP rows); split-K slabs: up to 8 of [MTTS_PFCAP][Npad] fp32
     size_t pmax = (size_t)8 * std::max(e->qkv_rows, round_up(H, 32));
     TRY(dalloc(&e->partial, pmax * MTTS_PFCAP));
+    TRY(dalloc(&e->partial2, (size_t)8 * round_up(H, 32) * MTTS_PFCAP));
+    TRY(dalloc((uint16_t**)&e->x2, (size_t)MTTS_MAXR * H));
+    TRY(dalloc((uint16_t**)&e->act_rm, (size_t)MTTS_MAXR * I));
     TRY(dalloc((uint16_t**)&e->x, (size_t)MTTS_PFCAP * H));
     TRY(dalloc((uint16_t**)&e->xn, (size_t)MTTS_PFCAP * H));
     TRY(dalloc((uint16_t**)&e->xh, (size_t)MTTS_RCAP * H));
@@ -367,7 +379,7 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
         hipFree(l.ln_in); hipFree(l.ln_post); hipFree(l.qn); hipFree(l.kn);
     }
     for (int c = 0; c < 8; ++c) hipFree(e->emb[c]);
-    void* ptrs[] = {e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
+    void* ptrs[] = {e->partial2, e->x2, e->act_rm, e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
                     e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->join_logits0, e->join_logits17, e->scores, e->stats,
                     e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
                     e->d_cur, e->d_gen, e->d_declog, e->d_forced, e->d_tf, e->d_bitmaps, e->d_scfg, e->d_pf_tokens,
@@ -489,6 +501,71 @@ static void prof_end(MttsEngine* e, hipStream_t st, hipEvent_t a) {
     hipEventRecord(a, st);
 }
 
+// ---- decode step for 1..SMALL_RP dialogues: six launches per layer instead of nine ---------------------------------
+// qkv GEMM [prologue: residual + slabs + input norm] -> scores -> P.V -> o_proj [prologue: chunk sum] ->
+// gate/up + SwiGLU [prologue: residual + slabs + post-attention norm] -> down_proj; the heads take the final norm as
+// their prologue.  The residual stream alternates between two buffers (a prologue's block (0,0) writes x' while the
+// other blocks still read x); the qkv slabs live in `partial` (the fused attention epilogue reads them), the o_proj /
+// down_proj slabs in `partial2`.  Same arithmetic as forward_rows, operation for operation.
+static bool small_path_fits(MttsEngine* e) {
+    const int H = e->H;
+    if (H > 8192 || H % 8 || e->I % 8) return false;
+    const int lim = 64 * 1024 - 33 * 1024;            // default dynamic-LDS budget next to the kernel's static 32.1 KiB
+    return mtts_small_lds_bytes(e->p_qkv, H, PRO_NORM) <= lim && mtts_small_lds_bytes(e->p_d, e->I, PRO_ROWS) <= lim &&
+           mtts_small_lds_bytes(e->p_o, e->nq * MTTS_HD, PRO_COMBINE) <= lim;
+}
+static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, hipStream_t st, int64_t kv_tokens_hint) {
+    const int H = e->H, I = e->I, nq = e->nq, nkv = e->nkv, Hp = round_up(H, 32), R = MTTS_MAXR;
+    const float eps = e->cfg.rms_norm_eps;
+    const float scale = 1.0f / sqrtf((float)MTTS_HD);
+    uint16_t* xa = (uint16_t*)e->x;                    // embed_norm has left the embedding sum here
+    uint16_t* xb = (uint16_t*)e->x2;
+    SmallPro base{};
+    base.rows = e->B; base.eps = eps; base.slab_npad = Hp;
+    for (int n = 0; n < e->L; ++n) {
+        Layer& l = e->layers[n];
+        uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
+        uint16_t* vc = (uint16_t*)e->vcache + e->layer_stride * n;
+        SmallPro pq = base;                            // input norm (+ the previous layer's down_proj slabs)
+        pq.x_in = xa; pq.x_out = xb; pq.slabs = e->partial2; pq.ksplit = n ? e->p_d.ksplit : 0; pq.norm_w = (const uint16_t*)l.ln_in;
+        launch_gemv_small(EPI_PARTIAL, PRO_NORM, e->p_qkv, l.wqkv, H, e->qkv_rows, e->qkv_rows, e->partial, nullptr, pq, st);
+        const bool fused = e->B * pages_bound <= e->fuse_qkv_max;
+        const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
+                         (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
+        if (!fused)
+            launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
+                            kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, st);
+        for (int phase = 1; phase <= 2; ++phase) {
+            hipEvent_t ev = nullptr;
+            prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
+            if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
+                            pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
+                            fused ? &fz : nullptr, phase, st))
+                return fail(MTTS_EINVAL, "attention group size not built");
+            prof_end(e, st, ev);
+        }
+        if (e->prof) {
+            e->prof_bytes[PROF_SCORES] += kv_tokens_hint * nkv * MTTS_HD * 2;
+            e->prof_bytes[PROF_PV] += kv_tokens_hint * nkv * MTTS_HD * 2;
+        }
+        SmallPro po = base;                            // o_proj: the chunk partials of P.V are summed in its prologue
+        po.opart = e->opart; po.meta = d_meta; po.nchunks_max = e->nchunks_max; po.nq = nq; po.pages_per_chunk = ATT_PB;
+        launch_gemv_small(EPI_PARTIAL, PRO_COMBINE, e->p_o, l.wo, nq * MTTS_HD, Hp, Hp, e->partial2, nullptr, po, st);
+        SmallPro pg = base;                            // post-attention norm (+ the o_proj slabs)
+        pg.x_in = xb; pg.x_out = xa; pg.slabs = e->partial2; pg.ksplit = e->p_o.ksplit; pg.norm_w = (const uint16_t*)l.ln_post;
+        launch_gemv_small(EPI_SILU_RM, PRO_NORM, e->p_gu, l.wgu, H, 2 * I, 2 * I, nullptr, (uint16_t*)e->act_rm, pg, st);
+        SmallPro pd = base;
+        pd.xrows = (const uint16_t*)e->act_rm;
+        launch_gemv_small(EPI_PARTIAL, PRO_ROWS, e->p_d, l.wd, I, Hp, Hp, e->partial2, nullptr, pd, st);
+    }
+    SmallPro ph = base;                                // final norm (+ the last down_proj slabs) in front of the 8 heads
+    ph.x_in = xa; ph.x_out = nullptr; ph.slabs = e->partial2; ph.ksplit = e->p_d.ksplit; ph.norm_w = (const uint16_t*)e->final_norm;
+    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h0, e->head0, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, ph, st);
+    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h17, e->heads17, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, ph, st);
+    HIPCHK(hipGetLastError());
+    return MTTS_OK;
+}
+
 // ---- one forward pass: R rows = decode rows (<= MTTS_RCAP, one dialogue each) or a prefill pass (<= MTTS_PFCAP) ----
 // heads: 0 none, 1 from xn (rows are sequences: decode), 2 from hlast (end of prefill)
 static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d_meta, int R, int pages_bound,
@@ -503,6 +580,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     // depend on how many rows (other dialogues) share its pass
     const bool tiled = heads != 1;
     launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, st);
+    if (heads == 1 && e->B <= e->small_rows && small_path_fits(e)) return forward_small(e, d_meta, pages_bound, st, kv_tokens_hint);
     for (int n = 0; n < e->L; ++n) {
         Layer& l = e->layers[n];
         uint16_t* kc = (uint16_t*)e->kcache + e->layer_stride * n;
@@ -593,7 +671,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     if (max_length <= base) return fail(MTTS_EINVAL, "max_length %d leaves no room to generate (prompt slots %d)", max_length, base);
     // a dialogue whose EOS falls within 7 steps of max_length keeps stepping until its flush is through
     // (`unfinished | needs_additional_steps > 0`, modeling_asteroid.py:165-168)
-    const int max_steps = max_length - base + FLUSH_STEPS;
+    const int max_steps = max_length - base + LINGER_STEPS;
     e->B = B; e->T = T; e->base_length = base; e->max_length = max_length; e->max_steps = max_steps;
     e->seed = seed; e->steps_issued = 0; e->has_forced = false;
     e->n_real.assign(B, 0);
@@ -789,7 +867,7 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
         std::vector<SeqState> ss(e->B);
         HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
         for (int b = 0; b < e->B; ++b)
-            if (e->slot_live[b] && ss[b].step > 0 && !ss[b].unfinished) { e->slot_live[b] = 0; pool_release(e, b); }
+            if (e->slot_live[b] && ss[b].step > 0 && !ss[b].unfinished && ss[b].active != 2) { e->slot_live[b] = 0; pool_release(e, b); }
     }
     if (steps_done) *steps_done = e->h_ls->step;
     if (all_finished) *all_finished = e->h_ls->done;

@@ -103,6 +103,215 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small-batch decode GEMM (1..SMALL_RP rows): the same weight stream and MFMA tile as gemm_skinny_kernel, but
+//   * the B operand (activations) is built by a PROLOGUE into LDS, compact [k/8][SMALL_RP rows][8 bf16]:
+//       PRO_NORM     residual + split-K slabs of the previous Linear -> x', RMSNorm(x')*w   (replaces resid_norm_kernel)
+//       PRO_COMBINE  sum of the P.V chunk partials -> attention output                       (replaces attn_combine_kernel)
+//       PRO_ROWS     copy of a row-major activation (the SwiGLU output)
+//     every block redoes it (a few KiB per row) while its first weight tiles are in flight;
+//   * only the live rows are stored.
+// The prologues repeat the arithmetic of the kernels they replace, operation for operation and in the same order, so
+// the small path gives the same bits as the general path (tested).  MFMA lanes whose row is >= SMALL_RP feed zeros.
+// grid = (N/32, ksplit), block = WAVES*64 (WAVES 4 or 8: the norm prologue works in groups of 256 threads).
+// ---------------------------------------------------------------------------------------------------
+enum { EPI_SILU_RM = 3 };      // SwiGLU, row-major bf16 [rows][N/2] output
+
+template <int WAVES, int EPI, int PRO>
+__global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
+    const u32x4_t* __restrict__ Wp, int KT, int kt_per_split, int kt_per_wave, float* __restrict__ partial,
+    uint16_t* __restrict__ out, int Npad, int n_valid, SmallPro pr) {
+    __shared__ float red[WAVES][16][64];
+    __shared__ float sh[WAVES / 4][4];
+    extern __shared__ __attribute__((aligned(16))) u32x4_t xs[];       // [(kt - kt_base)*2 + half][SMALL_RP]
+    const int nt = blockIdx.x, ks = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kb0 = ks * kt_per_split;                                 // this block's k-tile range
+    int kt0 = kb0 + wave * kt_per_wave;
+    int kt1 = min(min(kt0 + kt_per_wave, (ks + 1) * kt_per_split), KT);
+    const int n = max(kt1 - kt0, 0);
+    constexpr int U = 8;
+    const u32x4_t* wp = Wp + ((size_t)nt * KT + kt0) * 64 + lane;
+    // the first weight tiles go out before the prologue: its round trips overlap theirs
+    u32x4_t a[U];
+    if (n >= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+    }
+    const int kt_base = (PRO == PRO_NORM) ? 0 : kb0;
+    if (PRO == PRO_NORM) {
+        const int H = KT * 16;
+        constexpr int G = WAVES / 4;                                   // rows handled at a time (256 threads each)
+        const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
+        const size_t kstride = (size_t)MTTS_PFCAP * pr.slab_npad;
+        const bool writer = nt == 0 && ks == 0 && pr.x_out != nullptr;
+        for (int r0 = 0; r0 < pr.rows; r0 += G) {
+            const int r = r0 + g;
+            const bool act = r < pr.rows;
+            constexpr int MAXC = 4;                                    // H <= 8192
+            float v[MAXC][8];
+            u32x4_t nw[MAXC];
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int i0 = c * 2048 + t * 8;
+                if (i0 < H && act) {
+                    const u32x4_t xo = *(const u32x4_t*)(pr.x_in + (size_t)r * H + i0);
+                    nw[c] = *(const u32x4_t*)(pr.norm_w + i0);
+                    if (pr.ksplit > 0) {
+                        const float* p0 = pr.slabs + (size_t)r * pr.slab_npad + i0;
+                        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+                        for (int k0 = 0; k0 < pr.ksplit; k0 += 8) {
+                            float4 ta[8], tb[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float* pk = p0 + (size_t)min(k0 + j, pr.ksplit - 1) * kstride;
+                                ta[j] = *(const float4*)pk;
+                                tb[j] = *(const float4*)(pk + 4);
+                            }
+                            if (k0 == 0) { sa = ta[0]; sb = tb[0]; }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (k0 + j < pr.ksplit && k0 + j > 0) {
+                                    sa.x += ta[j].x; sa.y += ta[j].y; sa.z += ta[j].z; sa.w += ta[j].w;
+                                    sb.x += tb[j].x; sb.y += tb[j].y; sb.z += tb[j].z; sb.w += tb[j].w;
+                                }
+                        }
+                        v[c][0] = rbf(bflo(xo.x) + rbf(sa.x)); v[c][1] = rbf(bfhi(xo.x) + rbf(sa.y));
+                        v[c][2] = rbf(bflo(xo.y) + rbf(sa.z)); v[c][3] = rbf(bfhi(xo.y) + rbf(sa.w));
+                        v[c][4] = rbf(bflo(xo.z) + rbf(sb.x)); v[c][5] = rbf(bfhi(xo.z) + rbf(sb.y));
+                        v[c][6] = rbf(bflo(xo.w) + rbf(sb.z)); v[c][7] = rbf(bfhi(xo.w) + rbf(sb.w));
+                    } else {                                           // first layer: x is the embedding sum itself
+                        v[c][0] = bflo(xo.x); v[c][1] = bfhi(xo.x); v[c][2] = bflo(xo.y); v[c][3] = bfhi(xo.y);
+                        v[c][4] = bflo(xo.z); v[c][5] = bfhi(xo.z); v[c][6] = bflo(xo.w); v[c][7] = bfhi(xo.w);
+                    }
+                    if (writer) {
+                        u32x4_t xn;
+                        xn.x = pack2(v[c][0], v[c][1]); xn.y = pack2(v[c][2], v[c][3]);
+                        xn.z = pack2(v[c][4], v[c][5]); xn.w = pack2(v[c][6], v[c][7]);
+                        *(u32x4_t*)(pr.x_out + (size_t)r * H + i0) = xn;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
+                }
+            }
+            // block_sum_256 of resid_norm_kernel, per group of 256 threads
+            ss = wave_sum(ss);
+            if ((t & 63) == 0) sh[g][t >> 6] = ss;
+            __syncthreads();
+            const float tot = sh[g][0] + sh[g][1] + sh[g][2] + sh[g][3];
+            __syncthreads();
+            const float inv = 1.0f / sqrtf(tot / (float)H + pr.eps);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int i0 = c * 2048 + t * 8;
+                if (i0 < H && act) {
+                    const u32x4_t w = nw[c];
+                    u32x4_t y;
+                    y.x = pack2(bflo(w.x) * rbf(v[c][0] * inv), bfhi(w.x) * rbf(v[c][1] * inv));
+                    y.y = pack2(bflo(w.y) * rbf(v[c][2] * inv), bfhi(w.y) * rbf(v[c][3] * inv));
+                    y.z = pack2(bflo(w.z) * rbf(v[c][4] * inv), bfhi(w.z) * rbf(v[c][5] * inv));
+                    y.w = pack2(bflo(w.w) * rbf(v[c][6] * inv), bfhi(w.w) * rbf(v[c][7] * inv));
+                    xs[(size_t)(i0 >> 3) * SMALL_RP + r] = y;
+                }
+            }
+        }
+    } else if (PRO == PRO_COMBINE) {
+        // element (r, k = head*128 + d) of this block's K slice: chunks summed in order, as attn_combine_kernel does
+        const int k_lo = kb0 * 16, k_hi = min((ks + 1) * kt_per_split, KT) * 16, len = k_hi - k_lo;
+        for (int idx = threadIdx.x; idx < pr.rows * len; idx += WAVES * 64) {
+            const int r = idx / len, k = k_lo + idx % len;
+            const int h = k >> 7, d = k & 127;
+            const RowMeta m = pr.meta[r];
+            const int npages = m.seq >= 0 ? (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE : 0;
+            const int nch = (npages + pr.pages_per_chunk - 1) / pr.pages_per_chunk;
+            const float* p = pr.opart + ((size_t)r * pr.nq + h) * pr.nchunks_max * MTTS_HD + d;
+            float sacc = 0.f;
+            for (int c0 = 0; c0 < nch; c0 += 8) {
+                float tt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tt[j] = p[(size_t)min(c0 + j, nch - 1) * MTTS_HD];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < nch) sacc += tt[j];
+            }
+            ((uint16_t*)xs)[((size_t)((k - k_lo) >> 3) * SMALL_RP + r) * 8 + (k & 7)] = f2bf(sacc);
+        }
+    } else if (PRO == PRO_ROWS) {
+        const int K = KT * 16;
+        const int g_lo = kb0 * 2, g_hi = min((ks + 1) * kt_per_split, KT) * 2, len = g_hi - g_lo;     // 16-byte groups
+        for (int idx = threadIdx.x; idx < pr.rows * len; idx += WAVES * 64) {
+            const int r = idx / len, gi = idx % len;
+            xs[(size_t)gi * SMALL_RP + r] = *(const u32x4_t*)(pr.xrows + (size_t)r * K + (size_t)(g_lo + gi) * 8);
+        }
+    }
+    __syncthreads();
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int row = lane & 31;
+    const bool has = row < SMALL_RP;
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    // lane's B fragment of k-tile kt: 16-byte group (kt - kt_base)*2 + (lane >> 5), its row
+    const u32x4_t* xl = xs + (size_t)((kt0 - kt_base) * 2 + (lane >> 5)) * SMALL_RP + (has ? row : 0);
+    int i = 0;
+    for (; i + U <= n; i += U) {
+        if (i > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
+        }
+        u32x4_t b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4_t t = xl[(size_t)(i + u) * 2 * SMALL_RP];
+            b[u] = has ? t : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a[u], *(bf16x8_t*)&b[u], acc, 0, 0, 0);
+    }
+    for (; i < n; ++i) {
+        const u32x4_t aw = __builtin_nontemporal_load(wp + (size_t)i * 64);
+        const u32x4_t t = xl[(size_t)i * 2 * SMALL_RP];
+        const u32x4_t bw = has ? t : zero;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&aw, *(bf16x8_t*)&bw, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const int l2 = lane;
+    if ((l2 & 31) >= pr.rows) return;                          // only live rows are stored
+    for (int q = wave; q < 4; q += WAVES) {                    // q: register quad 4q..4q+3
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = red[0][4 * q + j][l2];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) s += red[w][4 * q + j][l2];
+            v[j] = s;
+        }
+        const int orow = l2 & 31;
+        const int nl = 8 * q + 4 * (l2 >> 5);
+        const int n0 = nt * 32 + nl;
+        if (EPI == EPI_PARTIAL) {
+            *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + orow) * Npad + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (EPI == EPI_BF16) {
+            uint16_t* o = out + (size_t)orow * n_valid + n0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+        } else {                                               // EPI_SILU_RM: gate,up interleaved rows -> [rows][Npad/2]
+            uint32_t w2;
+            {
+                float g0 = rbf(v[0]), u0 = rbf(v[1]), g1 = rbf(v[2]), u1 = rbf(v[3]);
+                float a0 = rbf(g0 / (1.0f + expf(-g0))), a1 = rbf(g1 / (1.0f + expf(-g1)));
+                w2 = pack2(a0 * u0, a1 * u1);
+            }
+            *(uint32_t*)(out + (size_t)orow * (Npad >> 1) + (n0 >> 1)) = w2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Prefill GEMM: Y[R rows, N] = X[R, K] * W[N, K]^T for R up to MTTS_PFCAP rows per pass (compute-bound side of
 // the path: 2*R*N*K flops on the matrix cores against one read of W).  Same fragment layouts as the skinny
 // kernel, so W and X fragments are contiguous KiB loads straight into MFMA operands (no LDS): a block of
@@ -300,6 +509,37 @@ void launch_gemm(int epi, int mb, const GemmPlan& p, const void* Wp, const void*
     else launch_gemm_mb<EPI_SILU>(mb, p, Wp, Xp, K, Npad, n_valid, partial, out, st);
 }
 
+
+// Small-batch launch.  The plan's waves are raised to >= 4 (the norm prologue works in groups of 256 threads).
+// Returns the dynamic LDS bytes it needs, or -1 when the shape does not fit (the caller then takes the general path).
+int mtts_small_lds_bytes(const GemmPlan& p, int K, int pro) {
+    const int kts = pro == PRO_NORM ? K / 16 : p.kt_per_split;
+    return kts * 2 * SMALL_RP * 16;
+}
+template <int EPI, int PRO>
+static void launch_small_epi(const GemmPlan& p0, const void* Wp, int K, int Npad, int n_valid, float* partial, uint16_t* out,
+                             const SmallPro& pr, hipStream_t st) {
+    GemmPlan p = p0;
+    if (p.waves < 4) { p.waves = 4; p.kt_per_wave = (p.kt_per_split + 3) / 4; }
+    dim3 grid(Npad / 32, p.ksplit);
+    const int KT = K / 16;
+    const size_t lds = (size_t)mtts_small_lds_bytes(p, K, PRO);
+    if (p.waves == 8)
+        hipLaunchKernelGGL((gemv_small_kernel<8, EPI, PRO>), grid, dim3(512), lds, st, (const u32x4_t*)Wp, KT, p.kt_per_split,
+                           p.kt_per_wave, partial, out, Npad, n_valid, pr);
+    else
+        hipLaunchKernelGGL((gemv_small_kernel<4, EPI, PRO>), grid, dim3(256), lds, st, (const u32x4_t*)Wp, KT, p.kt_per_split,
+                           p.kt_per_wave, partial, out, Npad, n_valid, pr);
+}
+// the combinations the decode step uses
+void launch_gemv_small(int epi, int pro, const GemmPlan& p, const void* Wp, int K, int Npad, int n_valid, float* partial,
+                       uint16_t* out, const SmallPro& pr, hipStream_t st) {
+    if (epi == EPI_PARTIAL && pro == PRO_NORM) launch_small_epi<EPI_PARTIAL, PRO_NORM>(p, Wp, K, Npad, n_valid, partial, out, pr, st);
+    else if (epi == EPI_PARTIAL && pro == PRO_COMBINE) launch_small_epi<EPI_PARTIAL, PRO_COMBINE>(p, Wp, K, Npad, n_valid, partial, out, pr, st);
+    else if (epi == EPI_PARTIAL && pro == PRO_ROWS) launch_small_epi<EPI_PARTIAL, PRO_ROWS>(p, Wp, K, Npad, n_valid, partial, out, pr, st);
+    else if (epi == EPI_SILU_RM && pro == PRO_NORM) launch_small_epi<EPI_SILU_RM, PRO_NORM>(p, Wp, K, Npad, n_valid, partial, out, pr, st);
+    else if (epi == EPI_BF16 && pro == PRO_NORM) launch_small_epi<EPI_BF16, PRO_NORM>(p, Wp, K, Npad, n_valid, partial, out, pr, st);
+}
 
 // Tiled launch for R > 128 rows (prefill passes).  ksplit only where the grid would leave most CUs idle.
 int mtts_tile_ksplit(int Npad, int K, int R) {

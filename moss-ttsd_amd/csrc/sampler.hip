@@ -127,7 +127,9 @@ __device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const 
     } else {
         if (ls->done) return false;
         const SeqState sq = seqs[b];
-        if (!sq.active || !sq.unfinished) return false;     // its tokens are forced by the state machine anyway
+        // finished rows get padding from the state machine; a row that finished AT max_length without a flush behind it
+        // (active == 2) is still evaluated, as in the reference: see update_kernel
+        if (!sq.active || !(sq.unfinished || sq.active == 2)) return false;
         x.c = c_in; x.step = sq.step;
         x.seed = sq.seed; x.row_id = (uint32_t)sq.row_id;
         x.V = (x.c == 0) ? V0 : Vs;
@@ -506,8 +508,15 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
         } else {
             const int step = s.step;
             int tok[8];
+            // The reference evaluates EVERY row of a static batch at every step (finished ones too) and tests their
+            // channel-0 pick for "not a speech token" (:140-141) before it overwrites the row with padding (:155-158).
+            // A row that was finished by max_length (needs_additional_steps still -1) is thereby resurrected for a
+            // 7-step flush as soon as its pick is a non-speech token (`unfinished | nas > 0`, :168), while the rest of
+            // the batch is still running.  Such rows are kept in the forward pass (active == 2); rows finished by EOS
+            // have nas == 0, can never come back, and are skipped for good.
+            const bool linger = s.active == 2;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) tok[c] = s.unfinished ? decisions[b * 8 + c] : 0;
+            for (int c = 0; c < 8; ++c) tok[c] = (s.unfinished || linger) ? decisions[b * 8 + c] : 0;
             const size_t slot = ((size_t)b * cap + step) * 8;
             const bool as_draw = forced && ls->forced_draw;
             if (as_draw) {          // the log keeps the raw draws; the reference's history drives the state machine
@@ -520,7 +529,7 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
             }
             // :140-141
             const bool speech = tok[0] >= sp_lo && tok[0] < sp_hi;
-            if (s.unfinished && !speech && s.nas < 0) s.nas = 7;
+            if ((s.unfinished || linger) && !speech && s.nas < 0) s.nas = 7;
             // :143-145 teacher forcing of the delayed prompt tail (first 7 steps)
             if (step < 7) {
 #pragma unroll
@@ -565,9 +574,13 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
             s.unfinished = (s.unfinished && !stopping) ? 1 : 0;
             if (s.nas > 0) s.unfinished = 1;
             s.step = step + 1;
-            if (ls->continuous && !s.unfinished) s.active = 0;      // scheduler mode: the slot is free again
+            if (ls->continuous) {
+                if (!s.unfinished) s.active = 0;                     // scheduler mode: the slot is free again
+            } else {
+                s.active = (!s.unfinished && s.nas < 0) ? 2 : 1;     // static batch: finished at max_length, may come back
+            }
             // the forward that follows appends this token to the cache at position kv_len
-            meta[b].seq = s.unfinished ? b : -1;
+            meta[b].seq = (s.unfinished || s.active == 2) ? b : -1;
             meta[b].pos = s.kv_len;
             meta[b].last = 1;
             s.kv_len += 1;

@@ -178,7 +178,7 @@ class AsteroidTTSInstruct:
         seed = self._next_seed(seed)
         ids = input_ids.detach().cpu().numpy()
         msk = attention_mask.detach().cpu().numpy()
-        eng = self._get_engine(B, int(max_length) + 7)
+        eng = self._get_engine(B, int(max_length) + 14)
         if B <= self.MAX_ENGINE_BATCH:
             # one static batch, the reference's semantics: finished rows emit (eos, 1024 x 7) until the batch ends
             out = eng.generate(ids, msk, int(max_length), layers=layers, do_samples=do_samples, seed=seed)
@@ -207,7 +207,7 @@ class AsteroidTTSInstruct:
         pads = [int(np.argmax(msk[b, :base] > 0)) for b in range(B)]
         prompts = [ids[b, pads[b]:] for b in range(B)]
         new = max_length - T
-        cb = ContinuousBatcher(eng, slots=self.MAX_ENGINE_BATCH, gen_cap=max_length - base + 8, layers=layers,
+        cb = ContinuousBatcher(eng, slots=self.MAX_ENGINE_BATCH, gen_cap=max_length - base + 8, layers=layers,   # max_new + 7 flush steps
                                do_samples=do_samples)
         res = cb.run(prompts, new, base_seed=seed)
         G = max(r.shape[0] - (T - pads[b] - 7) for b, r in enumerate(res))

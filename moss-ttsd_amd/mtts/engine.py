@@ -51,7 +51,7 @@ class Engine:
                   "eos_token_id"):
             setattr(c, k, int(cfg[k]))
         c.speech_range_lo, c.speech_range_hi = int(cfg["speech_token_range"][0]), int(cfg["speech_token_range"][1])
-        c.max_position = int(max_seq_len) + 16
+        c.max_position = int(max_seq_len) + 24
         c.rms_norm_eps = float(cfg["rms_norm_eps"])
         c.max_batch, c.max_seq_len = int(max_batch), int(max_seq_len)
         c.kv_pool_pages = int(kv_pool_pages)          # 0: every slot can reach max_seq_len at once
@@ -105,7 +105,8 @@ class Engine:
         run); decisions are then the raw draws."""
         ids, m = self._host_inputs(input_ids, attention_mask)
         B, T, _ = ids.shape
-        cap = int(max_length) + 7          # a flush that starts within 7 steps of max_length runs to its end
+        cap = int(max_length) + 14         # flushes that start at / run past max_length (include/mtts.h: mtts_generate)
+        self._B = B
         capi.check(self.lib.mtts_set_forced_mode(self._h, 1 if (forced is not None and forced_as_draw) else 0))
         out = np.zeros((B, cap, 8), dtype=np.int64)
         out_len = C.c_int32(0)

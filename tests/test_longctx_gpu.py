@@ -111,10 +111,14 @@ def test_shuffled_page_table_gives_identical_tokens(monkeypatch):
         eng = Engine(cfg, max_batch=4, max_seq_len=640)
         eng.bind_state_dict(w)
         g = eng.generate(ids, mask, max_length)
-        t, n = eng.page_table(4)
-        tables.append([t[b, :n[b]].tolist() for b in range(3)])
         s = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=9)
         outs.append((g, s))
+        eng.begin(ids, mask, max_length)                        # pages of a run in flight (finished rows return theirs)
+        eng.step(70)
+        eng.sync_state()
+        t, n = eng.page_table(4)
+        tables.append([t[b, :n[b]].tolist() for b in range(3)])
+        assert [len(r) for r in tables[-1]] == [(x - 7 + 70 + 63) // 64 for x in (330, 150, 257)]
         eng.close()
     assert outs[0][0].shape[1] - (ids.shape[1] - 7) >= 200
     for k in (1, 2):
@@ -154,7 +158,7 @@ def test_kv_page_pool_oversubscribed_equals_standalone():
     total, free0, per_seq = eng.kv_pool_state()
     assert (total, free0, per_seq) == (30, 30, 11)
     worst = sum((p.shape[0] - 7 + m + 7 + 63) // 64 for p, m in zip(prompts, mnts))
-    assert worst > 3 * total                                   # far more than the pool if reserved up front
+    assert worst > 2.5 * total                                 # far more than the pool if reserved up front
     for layers, ds in ((None, None), ([dict(top_k=20, top_p=0.9, temperature=1.1, repetition_penalty=1.2)] * 8, [True] * 8)):
         cb = ContinuousBatcher(eng, slots=6, gen_cap=280, layers=layers, do_samples=ds, steps_per_poll=8)
         seeds = list(range(300, 316))
