@@ -59,7 +59,11 @@ typedef struct MttsConfig {
     int32_t kv_pool_pages;         /* 64-token KV pages in the pool shared by all sequences; 0 = max_batch x pages(max_seq_len),
                                       i.e. every slot can reach max_seq_len at once.  A smaller pool serves short dialogues
                                       with less memory: pages are taken on demand and returned when a dialogue finishes */
+    int32_t dtype;                 /* MTTS_DTYPE_BF16 (0, the reference default) or MTTS_DTYPE_F32 (`inference.py --dtype fp32`,
+                                      inference.py:27-40): fp32 weights, arithmetic, K/V pages and logits -- the strict-parity mode */
 } MttsConfig;
+#define MTTS_DTYPE_BF16 0
+#define MTTS_DTYPE_F32 1
 
 /* generation_config.layers[i] / do_samples[i] (modeling_asteroid.py:95-106).
  * A field <= 0 (or top_k == 0) means "processor absent". */
@@ -90,6 +94,8 @@ int32_t mtts_engine_destroy(MttsEngine* e);
  * parameter materialisation (generation_utils.py:18). */
 int32_t mtts_bind_weight(MttsEngine* e, const char* name, const void* dev_bf16,
                          int64_t rows, int64_t cols, void* stream);
+/* (an MTTS_DTYPE_F32 engine takes fp32 row-major tensors through the same calls: dev_bf16 / dev_cos_bf16 / dev_sin_bf16
+ * then point to floats, and the engine keeps plain copies) */
 /* RoPE table cos|sin, bf16 [max_position][64] each, computed by the host the
  * way Qwen3RotaryEmbedding does (fp32 -> bf16). */
 int32_t mtts_bind_rope(MttsEngine* e, const void* dev_cos_bf16, const void* dev_sin_bf16,
@@ -125,6 +131,8 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
 int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_steps, int32_t* n_steps);
 /* last forward's logits: bf16 bits, channel 0 [B,vocab_size], channels 1..7 [7,B,speech_vocab_size] */
 int32_t mtts_read_logits(MttsEngine* e, uint16_t* host_logits0, uint16_t* host_logits17, void* stream);
+/* the same for an MTTS_DTYPE_F32 engine: fp32 logits */
+int32_t mtts_read_logits_f32(MttsEngine* e, float* host_logits0, float* host_logits17, void* stream);
 /* ---- continuous batching: slots are refilled while other dialogues are mid-flight ---------
  * mtts_sched_open: B empty slots, gen_cap rows of token storage each.  mtts_slot_submit: prefill ONE delay-shifted
  * prompt (host int64 [T][8], no padding) into an empty slot; its Philox stream is (seed; step, 0, channel).

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["gemm.hip", "layer.hip", "attn.hip", "sampler.hip", "engine.hip", "codec.hip"]
+SRC = ["gemm.hip", "layer.hip", "attn.hip", "sampler.hip", "f32path.hip", "engine.hip", "codec.hip"]
 OUT = os.path.join(HERE, "lib", "libmtts.so")
 
 

@@ -340,6 +340,14 @@ static void gemm_f32(hipStream_t st, bool b_kn, const float* A, const float* W, 
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, g);
 }
 
+// exact-f32 MFMA GEMM for the AR engine's fp32 mode (f32path.hip): C[M,N] (row stride ldc) = A[M,K] * W[N,K]^T
+void mtts_gemm_f32_exact(hipStream_t st, const float* A, const float* W, float* C, int M, int N, int K, long ldc) {
+    const int keep = g_gemm_split;
+    g_gemm_split = 0;
+    gemm_f32(st, false, A, W, C, M, N, K, K, K, ldc);
+    g_gemm_split = keep;
+}
+
 // ------------------------------------------------------------------------------------
 // Row kernels
 // ------------------------------------------------------------------------------------

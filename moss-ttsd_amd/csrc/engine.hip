@@ -51,7 +51,7 @@ int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* pag
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
                 const QkvFuse* fuse, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
-struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, pad1; };
+struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, logits_f32; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
 #define SAMP_CAND 4096
 #define SAMP_NS 32
@@ -71,6 +71,19 @@ void launch_update(const int32_t* decisions, int32_t* dec_log, const int32_t* fo
 
 void launch_export_codes(const int32_t* gen, int64_t* codes, int B, int first, int n, int speech_offset, int clamp_hi,
                          int cap, hipStream_t st);
+void launch_f32_embed_norm(const int32_t* tokens, const RowMeta* meta, const float* const* tables, const float* norm_w, float* x,
+                           float* xn, int R, int H, float eps, hipStream_t st);
+void launch_f32_resid_norm(const float* y, float* x, const float* norm_w, float* xn, float* hlast, const RowMeta* meta, int R,
+                           int H, float eps, hipStream_t st);
+void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, hipStream_t st);
+void launch_f32_qkv_post(const float* qkv, int ldq, const RowMeta* meta, const float* qnw, const float* knw, const float* cosb,
+                         const float* sinb, float* qbuf, float* kcache, float* vcache, const int32_t* page_table, int max_pages,
+                         int total_pages, int R, int nq, int nkv, float eps, hipStream_t st);
+void launch_f32_attn(const float* qbuf, const float* kcache, const float* vcache, const int32_t* page_table, const RowMeta* meta,
+                     float* scores, float* out, int R, int max_pages, int total_pages, int nq, int nkv, float scale, int Lmax,
+                     hipStream_t st);
+void launch_f32_swiglu(const float* gu, float* act, int R, int I, hipStream_t st);
+#define MTTS_PF32CAP 256       // rows of a prefill pass in the fp32 engine (bounds its fp32 score scratch)
 struct PageEdits { int32_t n; int32_t idx[31]; int32_t val[31]; };     // page-table entries handed over as launch arguments
 void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st);
 #define FLUSH_STEPS 7          // a dialogue whose EOS falls within 7 steps of max_length still runs its delay-pattern flush (modeling_asteroid.py:165-168)
@@ -138,6 +151,16 @@ struct MttsEngine {
     std::vector<char> slot_live;        // host's view: the slot holds a dialogue that may still step
     PageEdits pending_edits;            // table entries not yet on the device
     int forced_draw = 0;
+    // ---- MTTS_DTYPE_F32 engine (f32path.hip): plain fp32 copies of everything, no packed layouts ----
+    bool f32 = false;
+    struct LayerF32 { float *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr, *ln_in = nullptr, *ln_post = nullptr, *qn = nullptr, *kn = nullptr; };
+    std::vector<LayerF32> lf;
+    float* embf[8] = {nullptr};
+    const float** d_tables_f = nullptr;
+    float *final_norm_f = nullptr, *rope_cos_f = nullptr, *rope_sin_f = nullptr;
+    float *kcache_f = nullptr, *vcache_f = nullptr;
+    float *xf = nullptr, *xnf = nullptr, *qkvf = nullptr, *qbuf_f = nullptr, *attnf = nullptr, *yf = nullptr, *guf = nullptr,
+          *actf = nullptr, *hlast_f = nullptr, *scores_f = nullptr;
     // generation state
     SeqState* d_seqs = nullptr;
     RowMeta* d_meta = nullptr;          // decode rows
@@ -262,6 +285,66 @@ static void pool_release(MttsEngine* e, int b) {
     e->n_pages[b] = 0;
 }
 
+// ---- MTTS_DTYPE_F32 engine: allocation, binding, forward (kernels: f32path.hip) -------------------------------------
+static int create_f32(MttsEngine* e) {
+    const size_t H = e->H, I = e->I, D = MTTS_HD;
+    e->lf.resize(e->L);
+    for (auto& l : e->lf) {
+        TRY(dalloc(&l.wqkv, (size_t)e->qkv_rows * H, false));
+        TRY(dalloc(&l.wo, H * e->nq * D, false));
+        TRY(dalloc(&l.wgu, 2 * I * H, false));
+        TRY(dalloc(&l.wd, H * I, false));
+        TRY(dalloc(&l.ln_in, H)); TRY(dalloc(&l.ln_post, H)); TRY(dalloc(&l.qn, D)); TRY(dalloc(&l.kn, D));
+    }
+    TRY(dalloc(&e->embf[0], (size_t)e->V0 * H, false));
+    for (int ch = 1; ch < 8; ++ch) TRY(dalloc(&e->embf[ch], (size_t)e->Vs * H, false));
+    TRY(dalloc(&e->final_norm_f, H));
+    TRY(dalloc(&e->d_tables_f, 8));
+    HIPCHK(hipMemcpy((void*)e->d_tables_f, e->embf, 8 * sizeof(void*), hipMemcpyHostToDevice));
+    const size_t P = MTTS_PF32CAP;
+    TRY(dalloc(&e->xf, P * H)); TRY(dalloc(&e->xnf, P * H)); TRY(dalloc(&e->yf, P * H));
+    TRY(dalloc(&e->qkvf, P * e->qkv_rows)); TRY(dalloc(&e->qbuf_f, P * e->nq * D)); TRY(dalloc(&e->attnf, P * e->nq * D));
+    TRY(dalloc(&e->guf, P * 2 * I)); TRY(dalloc(&e->actf, P * I));
+    TRY(dalloc(&e->hlast_f, (size_t)MTTS_RCAP * H));
+    TRY(dalloc((float**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
+    TRY(dalloc((float**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
+    return 0;
+}
+
+static int forward_rows_f32(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d_meta, int R, int heads, hipStream_t st) {
+    const int H = e->H, I = e->I, nq = e->nq, nkv = e->nkv;
+    const float eps = e->cfg.rms_norm_eps, scale = 1.0f / sqrtf((float)MTTS_HD);
+    const int Lmax = e->max_pages * MTTS_PAGE;
+    launch_f32_embed_norm(d_tokens, d_meta, e->d_tables_f, e->lf[0].ln_in, e->xf, e->xnf, R, H, eps, st);
+    for (int n = 0; n < e->L; ++n) {
+        auto& l = e->lf[n];
+        float* kc = e->kcache_f + e->layer_stride * n;
+        float* vc = e->vcache_f + e->layer_stride * n;
+        launch_f32_linear(l.wqkv, e->xnf, e->qkvf, R, e->qkv_rows, H, e->qkv_rows, st);
+        launch_f32_qkv_post(e->qkvf, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos_f, e->rope_sin_f, e->qbuf_f, kc, vc,
+                            e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, st);
+        launch_f32_attn(e->qbuf_f, kc, vc, e->d_page_table, d_meta, e->scores_f, e->attnf, R, e->max_pages, e->total_pages, nq,
+                        nkv, scale, Lmax, st);
+        launch_f32_linear(l.wo, e->attnf, e->yf, R, H, nq * MTTS_HD, H, st);
+        launch_f32_resid_norm(e->yf, e->xf, l.ln_post, e->xnf, nullptr, d_meta, R, H, eps, st);
+        launch_f32_linear(l.wgu, e->xnf, e->guf, R, 2 * I, H, 2 * I, st);
+        launch_f32_swiglu(e->guf, e->actf, R, I, st);
+        launch_f32_linear(l.wd, e->actf, e->yf, R, H, I, H, st);
+        const bool lastl = n == e->L - 1;
+        launch_f32_resid_norm(e->yf, e->xf, lastl ? e->final_norm_f : e->lf[n + 1].ln_in, e->xnf, lastl ? e->hlast_f : nullptr,
+                              d_meta, R, H, eps, st);
+    }
+    if (heads) {
+        // decode rows are the dialogues themselves (row b = slot b); after a prefill the last tokens' states are in hlast
+        const float* xin = heads == 1 ? e->xnf : e->hlast_f;
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0, e->B, e->V0, H, e->V0, st);
+        for (int c = 1; c < 8; ++c)
+            launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)(c - 1) * e->Vs_pad, e->B, e->Vs, H, 7 * e->Vs_pad, st);
+    }
+    HIPCHK(hipGetLastError());
+    return MTTS_OK;
+}
+
 int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out) {
     if (!c || !out) return fail(MTTS_EINVAL, "null argument");
     if (c->head_dim != MTTS_HD) return fail(MTTS_EINVAL, "head_dim must be 128 (got %d)", c->head_dim);
@@ -289,7 +372,11 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->qkv_rows = (e->nq + 2 * e->nkv) * MTTS_HD;
     e->layers.resize(e->L);
     const int H = e->H, I = e->I;
+    if (c->dtype != MTTS_DTYPE_BF16 && c->dtype != MTTS_DTYPE_F32) return fail(MTTS_EINVAL, "dtype %d not built (bf16 = 0, fp32 = 1)", c->dtype);
+    e->f32 = c->dtype == MTTS_DTYPE_F32;
+    if (e->f32) TRY(create_f32(e));
     // packed weights (zeroed: padding rows must be zero)
+    if (!e->f32)
     for (auto& l : e->layers) {
         TRY(dalloc((uint16_t**)&l.wqkv, (size_t)e->qkv_rows * H));
         TRY(dalloc((uint16_t**)&l.wo, (size_t)H * e->nq * MTTS_HD));
@@ -300,6 +387,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
         TRY(dalloc((uint16_t**)&l.qn, (size_t)MTTS_HD));
         TRY(dalloc((uint16_t**)&l.kn, (size_t)MTTS_HD));
     }
+    if (!e->f32) {
     TRY(dalloc((uint16_t**)&e->emb[0], (size_t)e->V0 * H, false));
     for (int ch = 1; ch < 8; ++ch) TRY(dalloc((uint16_t**)&e->emb[ch], (size_t)e->Vs * H, false));
     TRY(dalloc((uint16_t**)&e->head0, (size_t)e->V0_pad * H));
@@ -307,6 +395,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->final_norm, (size_t)H));
     TRY(dalloc(&e->d_tables, 8));
     HIPCHK(hipMemcpy((void*)e->d_tables, e->emb, 8 * sizeof(void*), hipMemcpyHostToDevice));
+    }
     // plans
     e->p_qkv = mtts_plan_gemm(e->qkv_rows, H, 0);
     e->p_o = mtts_plan_gemm(round_up(H, 32), e->nq * MTTS_HD, 0);
@@ -316,6 +405,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
     // activations hold a whole prefill pass (MTTS_PFCAP rows); split-K slabs: up to 8 of [MTTS_PFCAP][Npad] fp32
     size_t pmax = (size_t)8 * std::max(e->qkv_rows, round_up(H, 32));
+    if (!e->f32) {
     TRY(dalloc(&e->partial, pmax * MTTS_PFCAP));
     TRY(dalloc(&e->partial2, (size_t)8 * round_up(H, 32) * MTTS_PFCAP));
     TRY(dalloc((uint16_t**)&e->x2, (size_t)MTTS_MAXR * H));
@@ -331,23 +421,32 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
     TRY(dalloc((uint16_t**)&e->join_logits0, (size_t)MTTS_MAXR * e->V0));
     TRY(dalloc((uint16_t**)&e->join_logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
+    }
     // KV pool
     e->max_pages = (c->max_seq_len + MTTS_PAGE - 1) / MTTS_PAGE + 1;
     e->total_pages = c->kv_pool_pages > 0 ? c->kv_pool_pages : e->max_pages * c->max_batch;
     if (c->kv_pool_pages < 0) return fail(MTTS_EINVAL, "kv_pool_pages must be >= 0");
     e->nchunks_max = (e->max_pages + ATT_PB - 1) / ATT_PB;
     e->layer_stride = (size_t)e->total_pages * e->nkv * MTTS_PAGE * MTTS_HD;
-    TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
-    TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
+    if (e->f32) {
+        TRY(dalloc(&e->kcache_f, e->layer_stride * e->L));
+        TRY(dalloc(&e->vcache_f, e->layer_stride * e->L));
+        TRY(dalloc(&e->scores_f, (size_t)MTTS_PF32CAP * e->nq * e->max_pages * MTTS_PAGE, false));
+    } else {
+        TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
+        TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
+    }
     TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
     e->n_pages.assign(c->max_batch, 0);
     e->slot_live.assign(c->max_batch, 0);
     e->pending_edits.n = 0;
     pool_reset(e);
+    if (!e->f32) {
     TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_PFCAP * e->nq * e->max_pages * MTTS_PAGE));
     TRY(dalloc(&e->stats, (size_t)MTTS_PFCAP * e->nq * e->max_pages * 2));
     TRY(dalloc(&e->opart, (size_t)MTTS_PFCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
+    }
     // state
     TRY(dalloc(&e->d_seqs, MTTS_RCAP));
     TRY(dalloc(&e->d_meta, MTTS_RCAP));
@@ -379,6 +478,13 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
         hipFree(l.ln_in); hipFree(l.ln_post); hipFree(l.qn); hipFree(l.kn);
     }
     for (int c = 0; c < 8; ++c) hipFree(e->emb[c]);
+    for (auto& l : e->lf) { hipFree(l.wqkv); hipFree(l.wo); hipFree(l.wgu); hipFree(l.wd); hipFree(l.ln_in); hipFree(l.ln_post); hipFree(l.qn); hipFree(l.kn); }
+    for (int c = 0; c < 8; ++c) hipFree(e->embf[c]);
+    {
+        void* fp[] = {(void*)e->d_tables_f, e->final_norm_f, e->rope_cos_f, e->rope_sin_f, e->kcache_f, e->vcache_f, e->xf, e->xnf, e->qkvf,
+                      e->qbuf_f, e->attnf, e->yf, e->guf, e->actf, e->hlast_f, e->scores_f};
+        for (void* q : fp) if (q) hipFree(q);
+    }
     void* ptrs[] = {e->partial2, e->x2, e->act_rm, e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
                     e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->join_logits0, e->join_logits17, e->scores, e->stats,
                     e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
@@ -399,11 +505,55 @@ static bool ends_with(const std::string& s, const char* suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// fp32 engine: plain row-major copies (q|k|v rows one after another, gate rows then up rows)
+static int bind_weight_f32(MttsEngine* e, const char* name_c, const float* src, int64_t rows, int64_t cols, hipStream_t st) {
+    std::string name(name_c);
+    const int64_t H = e->H, I = e->I, D = MTTS_HD;
+    auto put = [&](float* dst, int64_t r, int64_t c) -> int {
+        const bool vec = (c == 1) && ((rows == r && cols == 1) || (rows == 1 && cols == r));
+        if (!vec && !(rows == r && cols == c)) return fail(MTTS_EINVAL, "%s: expected [%lld,%lld] got [%lld,%lld]", name_c, (long long)r, (long long)c, (long long)rows, (long long)cols);
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)r * c * 4, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    int ch = -1;
+    if (sscanf(name_c, "model.embedding_list.%d.weight", &ch) == 1) {
+        if (ch < 0 || ch > 7) return fail(MTTS_EINVAL, "bad channel in %s", name_c);
+        TRY(put(e->embf[ch], ch == 0 ? e->V0 : e->Vs, H));
+        e->emb_bound |= 1 << ch;
+        return MTTS_OK;
+    }
+    if (name == "model.language_model.norm.weight") { TRY(put(e->final_norm_f, H, 1)); e->norm_bound = 1; return MTTS_OK; }
+    if (name.find("lm_heads.") == 0 || name == "model.language_model.embed_tokens.weight") return MTTS_OK;
+    int n = -1;
+    char rest[128];
+    if (sscanf(name_c, "model.language_model.layers.%d.%127s", &n, rest) == 2) {
+        if (n < 0 || n >= e->L) return fail(MTTS_EINVAL, "layer index out of range in %s", name_c);
+        auto& l = e->lf[n];
+        Layer& lb = e->layers[n];
+        std::string r(rest);
+        if (r == "input_layernorm.weight") { TRY(put(l.ln_in, H, 1)); lb.bound |= 1; }
+        else if (r == "post_attention_layernorm.weight") { TRY(put(l.ln_post, H, 1)); lb.bound |= 2; }
+        else if (r == "self_attn.q_norm.weight") { TRY(put(l.qn, D, 1)); lb.bound |= 4; }
+        else if (r == "self_attn.k_norm.weight") { TRY(put(l.kn, D, 1)); lb.bound |= 8; }
+        else if (r == "self_attn.q_proj.weight") { TRY(put(l.wqkv, e->nq * D, H)); lb.bound |= 16; }
+        else if (r == "self_attn.k_proj.weight") { TRY(put(l.wqkv + (size_t)e->nq * D * H, e->nkv * D, H)); lb.bound |= 32; }
+        else if (r == "self_attn.v_proj.weight") { TRY(put(l.wqkv + (size_t)(e->nq + e->nkv) * D * H, e->nkv * D, H)); lb.bound |= 64; }
+        else if (r == "self_attn.o_proj.weight") { TRY(put(l.wo, H, e->nq * D)); lb.bound |= 128; }
+        else if (r == "mlp.gate_proj.weight") { TRY(put(l.wgu, I, H)); lb.bound |= 256; }
+        else if (r == "mlp.up_proj.weight") { TRY(put(l.wgu + (size_t)I * H, I, H)); lb.bound |= 512; }
+        else if (r == "mlp.down_proj.weight") { TRY(put(l.wd, H, I)); lb.bound |= 1024; }
+        else return fail(MTTS_EINVAL, "unknown tensor %s", name_c);
+        return MTTS_OK;
+    }
+    return fail(MTTS_EINVAL, "unknown tensor %s", name_c);
+}
+
 int32_t mtts_bind_weight(MttsEngine* e, const char* name_c, const void* src, int64_t rows, int64_t cols, void* stream) {
     if (!e || !name_c || !src) return fail(MTTS_EINVAL, "null argument");
     HIPCHK(hipSetDevice(e->device));
     drop_graphs(e);
     hipStream_t st = S(stream);
+    if (e->f32) return bind_weight_f32(e, name_c, (const float*)src, rows, cols, st);
     std::string name(name_c);
     const int H = e->H, I = e->I, D = MTTS_HD;
     auto expect = [&](int64_t r, int64_t c) { return rows == r && cols == c; };
@@ -468,6 +618,15 @@ int32_t mtts_bind_rope(MttsEngine* e, const void* cosb, const void* sinb, int32_
     if (!e || !cosb || !sinb || rows < 1) return fail(MTTS_EINVAL, "bad rope table");
     HIPCHK(hipSetDevice(e->device));
     drop_graphs(e);
+    if (e->f32) {           // fp32 tables [rows][64], as Qwen3RotaryEmbedding leaves them before the cast to the model dtype
+        if (e->rope_cos_f) { hipFree(e->rope_cos_f); hipFree(e->rope_sin_f); }
+        TRY(dalloc(&e->rope_cos_f, (size_t)rows * 64, false));
+        TRY(dalloc(&e->rope_sin_f, (size_t)rows * 64, false));
+        HIPCHK(hipMemcpyAsync(e->rope_cos_f, cosb, (size_t)rows * 256, hipMemcpyDeviceToDevice, S(stream)));
+        HIPCHK(hipMemcpyAsync(e->rope_sin_f, sinb, (size_t)rows * 256, hipMemcpyDeviceToDevice, S(stream)));
+        e->rope_rows = rows;
+        return MTTS_OK;
+    }
     if (e->rope_cos) { hipFree(e->rope_cos); hipFree(e->rope_sin); }
     TRY(dalloc((uint16_t**)&e->rope_cos, (size_t)rows * 64, false));
     TRY(dalloc((uint16_t**)&e->rope_sin, (size_t)rows * 64, false));
@@ -579,6 +738,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
     // 1024-row pass: good from one dialogue's prompt up to a full pass): a prompt's hidden states then do not
     // depend on how many rows (other dialogues) share its pass
     const bool tiled = heads != 1;
+    if (e->f32) return forward_rows_f32(e, d_tokens, d_meta, heads == 1 ? e->B : R, heads, st);
     launch_embed_norm(d_tokens, d_meta, e->d_tables, e->layers[0].ln_in, e->x, e->xn, R, H, eps, st);
     if (heads == 1 && e->B <= e->small_rows && small_path_fits(e)) return forward_small(e, d_meta, pages_bound, st, kv_tokens_hint);
     for (int n = 0; n < e->L; ++n) {
@@ -751,7 +911,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
         std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
         for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0, base, max_length, b, 1, seed};
         HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
-        LoopState ls{0, 0, 0, B, 0, e->gen_cap, e->forced_draw, 0};
+        LoopState ls{0, 0, 0, B, 0, e->gen_cap, e->forced_draw, e->f32 ? 1 : 0};
         e->continuous = false;
         e->join_step.assign(MTTS_RCAP, 0);
         HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
@@ -767,8 +927,9 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     }
     // prefill: chunks of 32 flattened tokens; K/V of a chunk are written before its attention runs
     const int pages_bound = (e->max_real + MTTS_PAGE - 1) / MTTS_PAGE;
-    for (size_t off = 0; off < Mpad; off += MTTS_PFCAP) {
-        const int rows = (int)std::min<size_t>(MTTS_PFCAP, Mpad - off);     // multiple of MTTS_RCAP
+    const size_t pfcap = e->f32 ? MTTS_PF32CAP : MTTS_PFCAP;
+    for (size_t off = 0; off < Mpad; off += pfcap) {
+        const int rows = (int)std::min<size_t>(pfcap, Mpad - off);     // multiple of MTTS_RCAP
         const bool lastc = off + rows >= Mpad;
         TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, rows, pages_bound, lastc ? 2 : 0, st, 0));
     }
@@ -894,8 +1055,25 @@ int32_t mtts_read_generated(MttsEngine* e, int64_t* host_gen, int32_t capacity_s
     return read_rows(e, e->d_gen, host_gen, capacity_steps, n_steps);
 }
 
+int32_t mtts_read_logits_f32(MttsEngine* e, float* l0, float* l17, void* stream) {
+    if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    if (!e->f32) return fail(MTTS_ESTATE, "bf16 engine: use mtts_read_logits");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 4, hipMemcpyDeviceToHost));
+    if (l17) {
+        std::vector<float> tmp((size_t)MTTS_RCAP * 7 * e->Vs_pad);
+        HIPCHK(hipMemcpy(tmp.data(), e->logits17, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int c = 0; c < 7; ++c)
+            for (int b = 0; b < e->B; ++b)
+                memcpy(l17 + ((size_t)c * e->B + b) * e->Vs, tmp.data() + ((size_t)b * 7 + c) * e->Vs_pad, (size_t)e->Vs * 4);
+    }
+    return MTTS_OK;
+}
+
 int32_t mtts_read_logits(MttsEngine* e, uint16_t* l0, uint16_t* l17, void* stream) {
     if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    if (e->f32) return fail(MTTS_ESTATE, "fp32 engine: use mtts_read_logits_f32");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(S(stream)));
     if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 2, hipMemcpyDeviceToHost));
@@ -975,6 +1153,7 @@ int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfi
 // finishes leaves the batch at once (no finished-row padding) and its slot can be refilled.
 int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSamplerCfg* sampler, void* stream) {
     if (!e || !sampler) return fail(MTTS_EINVAL, "null argument");
+    if (e->f32) return fail(MTTS_EINVAL, "continuous batching is built for the bf16 engine only");
     TRY(mtts_weights_ready(e));
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = S(stream);
@@ -1254,6 +1433,7 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
 // when collecting PMC counters.
 extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
     if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
+    if (e->f32) return fail(MTTS_EINVAL, "measurement hook of the bf16 engine");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipDeviceSynchronize());
     const int cap = std::min(e->max_pages * MTTS_PAGE, e->rope_rows);          // positions the pages and the RoPE table hold
@@ -1277,6 +1457,7 @@ extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
 // does not; a train of launches does not have that bias.)
 extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters, float* avg_ms, int64_t* bytes_per_launch) {
     if (!e || !e->began || (phase != 1 && phase != 2) || iters < 1 || !avg_ms) return fail(MTTS_EINVAL, "attn_bench: bad argument");
+    if (e->f32) return fail(MTTS_EINVAL, "measurement hook of the bf16 engine");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipDeviceSynchronize());
     const float scale = 1.0f / sqrtf((float)MTTS_HD);

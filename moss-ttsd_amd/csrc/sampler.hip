@@ -39,7 +39,7 @@ struct LoopState {          // one per engine, device resident
     int32_t gen_cap;        // rows of generated-token storage per slot
     int32_t forced_draw;    // forced replay: 1 = the forced row replaces the step's raw draw BEFORE the state machine
                             //    (replay of a sampled reference run); 0 = it replaces the state machine's output
-    int32_t pad1;
+    int32_t logits_f32;     // the logits buffers hold fp32 (MTTS_DTYPE_F32 engine) instead of bf16
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -66,10 +66,11 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 }
 
 // Processed score of token i (everything except top-k / top-p, which act on the set).
-__device__ __forceinline__ float proc_score(const uint16_t* __restrict__ logits, int i, int mask_id,
+struct LogitsPtr { const void* p; int f32; };     // one row of logits: bf16 bit patterns, or fp32 in the fp32 engine
+__device__ __forceinline__ float proc_score(LogitsPtr logits, int i, int mask_id,
                                             const uint32_t* __restrict__ bitmap, float penalty, float temperature) {
     if (i == mask_id) return -INFINITY;
-    float s = bf2f(logits[i]);
+    float s = logits.f32 ? ((const float*)logits.p)[i] : bf2f(((const uint16_t*)logits.p)[i]);
     if (penalty > 0.f && (bitmap[i >> 5] >> (i & 31)) & 1u) s = (s < 0.f) ? s * penalty : s / penalty;
     if (temperature > 0.f) s = s / temperature;
     return s;
@@ -106,7 +107,7 @@ struct SampleScratch {
 };
 
 struct SampleCtx {         // resolved per (row, channel)
-    const uint16_t* lg;
+    LogitsPtr lg;
     const uint32_t* bm;
     int V, mask_id, step, c;
     float penalty, temp;
@@ -122,7 +123,7 @@ __device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const 
     if (single_vocab > 0) {            // unit-test entry: one logits matrix [rows][vocab]
         x.c = single_channel; x.step = single_step; x.V = single_vocab; x.mask_id = single_mask;
         x.seed = 0; x.row_id = (uint32_t)b;
-        x.lg = logits0 + (size_t)b * x.V;
+        x.lg = LogitsPtr{logits0 + (size_t)b * x.V, 0};
         x.bm = bitmaps ? bitmaps + (size_t)b * bm_words : nullptr;
     } else {
         if (ls->done) return false;
@@ -133,7 +134,11 @@ __device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const 
         x.c = c_in; x.step = sq.step;
         x.seed = sq.seed; x.row_id = (uint32_t)sq.row_id;
         x.V = (x.c == 0) ? V0 : Vs;
-        x.lg = (x.c == 0) ? logits0 + (size_t)b * V0 : logits17 + ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
+        {
+            const size_t off = (x.c == 0) ? (size_t)b * V0 : ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
+            const char* base = (const char*)((x.c == 0) ? logits0 : logits17);
+            x.lg = LogitsPtr{base + off * (ls->logits_f32 ? 4 : 2), ls->logits_f32};
+        }
         // modeling_asteroid.py:124-128 (hard-coded ids 1024 / 152694 as in the reference)
         x.mask_id = -1;
         if (x.c != 0 && x.step >= x.c) x.mask_id = 1024;

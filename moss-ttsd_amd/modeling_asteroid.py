@@ -113,23 +113,28 @@ class AsteroidTTSInstruct:
         self._engine_key = None
         self.device = torch.device("cpu")
         self.training = False
+        self.dtype = "bf16"             # "fp32": the strict-parity engine (from_pretrained(torch_dtype=torch.float32))
         self.sample_seed = None         # explicit Philox key for the next generate() (tests); None = from torch's seed
         self._calls = 0
 
     # ---- loading -----------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, attn_implementation=None, **_):
-        if torch_dtype not in (torch.bfloat16, None):
-            raise NotImplementedError("the MI355X engine computes in bf16 (the reference default); "
-                                      f"torch_dtype={torch_dtype} is not built")
+        if torch_dtype not in (torch.bfloat16, torch.float32, None):
+            raise NotImplementedError("the MI355X engine is built for bf16 (the reference default) and fp32 "
+                                      f"(inference.py --dtype); torch_dtype={torch_dtype} is not")
         if not os.path.isdir(model_path):
             raise FileNotFoundError(f"{model_path}: local checkpoint directory required (no network here)")
         cfg = AsteroidTTSConfig.from_pretrained(model_path)
-        return cls(cfg, _load_safetensors_dir(model_path), GenerationConfig.from_pretrained(model_path))
+        m = cls(cfg, _load_safetensors_dir(model_path), GenerationConfig.from_pretrained(model_path))
+        m.dtype = "fp32" if torch_dtype == torch.float32 else "bf16"
+        return m
 
     @classmethod
-    def from_state_dict(cls, cfg_dict, state_dict, generation_config=None):
-        return cls(AsteroidTTSConfig(**cfg_dict), state_dict, generation_config)
+    def from_state_dict(cls, cfg_dict, state_dict, generation_config=None, dtype="bf16"):
+        m = cls(AsteroidTTSConfig(**cfg_dict), state_dict, generation_config)
+        m.dtype = dtype
+        return m
 
     def eval(self):
         self.training = False
@@ -156,7 +161,7 @@ class AsteroidTTSInstruct:
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(self.config.to_dict(), max_batch=slots, max_seq_len=cap_len,
-                                  device=str(self.device))
+                                  device=str(self.device), dtype=self.dtype)
             self._engine.bind_state_dict(self._sd)
             self._engine_key = key
         return self._engine

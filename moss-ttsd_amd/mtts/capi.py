@@ -14,7 +14,7 @@ class MttsConfig(C.Structure):
         "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
         "num_key_value_heads", "head_dim", "channels", "speech_vocab_size", "speech_pad_token",
         "speech_range_lo", "speech_range_hi", "eos_token_id", "max_position")] + [
-        ("rms_norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_seq_len", C.c_int32), ("kv_pool_pages", C.c_int32)]
+        ("rms_norm_eps", C.c_float), ("max_batch", C.c_int32), ("max_seq_len", C.c_int32), ("kv_pool_pages", C.c_int32), ("dtype", C.c_int32)]
 
 
 class MttsSamplerCfg(C.Structure):
@@ -60,6 +60,7 @@ _SIGS = {
     "mtts_sync_state": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "mtts_read_generated": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mtts_read_logits": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_read_logits_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_sched_open": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(MttsSamplerCfg), C.c_void_p]),
     "mtts_slot_submit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     "mtts_slot_states": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),

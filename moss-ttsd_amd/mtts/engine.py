@@ -28,18 +28,24 @@ def sampler_cfgs(layers=None, do_samples=None):
     return arr
 
 
-def rope_tables(head_dim, theta, rows, device):
+def rope_tables(head_dim, theta, rows, device, dtype=torch.bfloat16):
     """cos/sin exactly as Qwen3RotaryEmbedding.forward builds them (transformers
-    modeling_qwen3.py:96-138): fp32 inv_freq, fp32 outer product, cos/sin, cast to bf16."""
+    modeling_qwen3.py:96-138): fp32 inv_freq, fp32 outer product, cos/sin, cast to the model dtype."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
     pos = torch.arange(rows, dtype=torch.float)
     freqs = (inv_freq[:, None] @ pos[None, :]).transpose(0, 1)            # [rows, 64]
-    return (freqs.cos().to(torch.bfloat16).contiguous().to(device),
-            freqs.sin().to(torch.bfloat16).contiguous().to(device))
+    return (freqs.cos().to(dtype).contiguous().to(device),
+            freqs.sin().to(dtype).contiguous().to(device))
 
 
 class Engine:
-    def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0", kv_pool_pages: int = 0):
+    def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0", kv_pool_pages: int = 0, dtype="bf16"):
+        """dtype "bf16" (the reference default) or "fp32" (`inference.py --dtype fp32`: fp32 weights, arithmetic,
+        K/V pages and logits -- the strict-parity mode, plain HBM-bound kernels)."""
+        if dtype not in ("bf16", "fp32"):
+            raise NotImplementedError(f"dtype {dtype!r} is not built (bf16, fp32)")
+        self.dtype = dtype
+        self.tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         if not torch.cuda.is_available():
             raise capi.MttsError("no GPU visible: the mtts engine only runs on MI355X (no CPU fallback)")
         self.cfg = cfg
@@ -55,9 +61,10 @@ class Engine:
         c.rms_norm_eps = float(cfg["rms_norm_eps"])
         c.max_batch, c.max_seq_len = int(max_batch), int(max_seq_len)
         c.kv_pool_pages = int(kv_pool_pages)          # 0: every slot can reach max_seq_len at once
+        c.dtype = 0 if dtype == "bf16" else 1
         self._h = C.c_void_p()
         capi.check(self.lib.mtts_engine_create(C.byref(c), self.device.index or 0, C.byref(self._h)))
-        cos, sin = rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position, self.device)
+        cos, sin = rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position, self.device, self.tdtype)
         torch.cuda.synchronize(self.device)
         capi.check(self.lib.mtts_bind_rope(self._h, cos.data_ptr(), sin.data_ptr(), c.max_position, None))
         torch.cuda.synchronize(self.device)
@@ -75,7 +82,7 @@ class Engine:
 
     # ---- weights -----------------------------------------------------------
     def bind(self, name: str, tensor: torch.Tensor):
-        t = tensor.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        t = tensor.to(device=self.device, dtype=self.tdtype).contiguous()
         rows, cols = (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.shape[0], 1)
         capi.check(self.lib.mtts_bind_weight(self._h, name.encode(), t.data_ptr(), rows, cols, None))
         torch.cuda.synchronize(self.device)     # the engine has packed its own copy; `t` may go
@@ -150,6 +157,11 @@ class Engine:
 
     def read_logits(self):
         V0, Vs = self.cfg["vocab_size"], self.cfg["speech_vocab_size"]
+        if self.dtype == "fp32":
+            l0 = np.zeros((self._B, V0), dtype=np.float32)
+            l17 = np.zeros((7, self._B, Vs), dtype=np.float32)
+            capi.check(self.lib.mtts_read_logits_f32(self._h, l0.ctypes.data, l17.ctypes.data, None))
+            return l0, l17
         l0 = np.zeros((self._B, V0), dtype=np.uint16)
         l17 = np.zeros((7, self._B, Vs), dtype=np.uint16)
         capi.check(self.lib.mtts_read_logits(self._h, l0.ctypes.data, l17.ctypes.data, None))

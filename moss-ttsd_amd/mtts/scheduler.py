@@ -8,10 +8,12 @@ are exactly what it would get alone (`Engine.generate` with batch 1 and the same
 depends on its neighbours.
 
 Admission is by free KV pages, not by slots alone: the pool (`Engine(kv_pool_pages=...)`) may hold far fewer pages
-than `slots x max_seq_len` tokens.  A prompt is admitted when its pages (plus one) are free; pages for generated
-tokens are taken as the dialogues grow.  If the pool runs dry mid-flight (`mtts_step` -> MTTS_ENOMEM) the dialogue
-with the fewest generated rows is evicted and re-queued: tokens are a function of (prompt, seed), so its re-run
-reproduces them.
+than `slots x max_seq_len` tokens.  A prompt is admitted when its pages are free with one page of headroom per
+resident dialogue (each of them opens a new page every 64 steps); pages for generated tokens are taken as the
+dialogues grow.  If the pool still runs dry mid-flight (`mtts_step` -> MTTS_ENOMEM) the dialogue with the fewest
+generated rows is evicted and re-queued -- tokens are a function of (prompt, seed), so its re-run reproduces them --
+and nothing new is admitted until a resident dialogue has finished (otherwise the evicted prompt would take the freed
+pages straight back).
 """
 from __future__ import annotations
 
@@ -41,12 +43,19 @@ class ContinuousBatcher:
         owner = [-1] * self.slots
         queue = list(range(n))
         steps = 0
-        _, _, _ = self.eng.kv_pool_state()
+        hold = False                                                  # after an eviction: wait for a dialogue to finish
+        polls = 0
         while queue or any(o >= 0 for o in owner):
+            polls += 1
+            if polls > 1_000_000:
+                raise capi.MttsError("continuous batcher made no progress (scheduling bug)")
             for s in range(self.slots):                               # refill free slots while pages last
-                if owner[s] < 0 and queue:
+                if owner[s] < 0 and queue and not hold:
                     i = queue[0]
                     ids = np.asarray(prompts[i], dtype=np.int64)
+                    live = sum(1 for o in owner if o >= 0)
+                    if live and self.eng.kv_pool_state()[1] < (ids.shape[0] - 7 + 64) // 64 + live + 1:
+                        break                                         # not enough headroom next to the residents
                     try:
                         self.eng.submit(s, ids, ids.shape[0] + int(mnt[i]), seed=int(seeds[i]))
                     except capi.MttsError as err:
@@ -73,6 +82,7 @@ class ContinuousBatcher:
                     queue.insert(0, owner[victim])
                     owner[victim] = -1
                     self.evictions += 1
+                    hold = True
             st = self.eng.slot_states()
             for s in range(self.slots):
                 if owner[s] >= 0 and not st[s, 0]:                    # left the batch: collect
@@ -81,5 +91,6 @@ class ContinuousBatcher:
                     ids = np.asarray(prompts[i], dtype=np.int64)
                     results[i] = np.concatenate([ids[:ids.shape[0] - 7], rows], axis=0)
                     owner[s] = -1
+                    hold = False
         self.engine_steps = steps
         return results

@@ -21,6 +21,6 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_struct_layouts_match_header():
     import ctypes as C
-    assert C.sizeof(capi.MttsConfig) == 18 * 4
+    assert C.sizeof(capi.MttsConfig) == 19 * 4
     assert C.sizeof(capi.MttsSamplerCfg) == 6 * 4
     assert C.sizeof(codec.MttsCodecConfig) == 32 * 4
