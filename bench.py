@@ -250,6 +250,21 @@ def dry_run(args, dist, world, rank):
         dist.destroy_process_group()
 
 
+def codec_cpu_baseline(codes_n=100):
+    """The codec oracle (numpy restatement of XY_Tokenizer.decode, full depth) on the host cores, one sequence of
+    `codes_n` codes (8 s of audio): the CPU figure beside the codec leg."""
+    from mtts import synth_codec
+    from oracle import codec_oracle as co
+    cfg = synth_codec.codec_config()
+    orc = co.CodecOracle(cfg, synth_codec.synth_weights(cfg, 5))
+    codes = np.random.default_rng(0).integers(0, 1024, (cfg["nq"], codes_n))
+    t0 = time.perf_counter()
+    y = orc.decode([codes])[0]
+    dt = time.perf_counter() - t0
+    return {"value": (y.shape[0] / 24000.0) / dt, "unit": "audio_seconds/s", "cores": host_cores(), "kind": "port",
+            "sample": f"numpy codec oracle, full depth, one sequence of {codes_n} codes ({codes_n * 0.08:.1f} s of audio) in {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +277,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--greedy", action="store_true",
+                    help="argmax on every channel instead of top-k/top-p sampling (BASELINE configs[1]: --batch 1 --context 2048 --greedy)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective rehearsal without the engine (CPU, gloo): every rank reports a fixed "
                          "synthetic step time; checks that --gpus N really runs N ranks (the result is marked invalid)")
@@ -329,7 +346,8 @@ def main():
                           + cfg["num_attention_heads"] * cfg["head_dim"] * H_ + 3 * H_ * I_)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.begin(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=42 + rank)
+    do_samples = [not args.greedy] * 8
+    eng.begin(ids, mask, max_length, layers=None if args.greedy else layers, do_samples=do_samples, seed=42 + rank)
     eng.sync_state()
     t_prefill = time.perf_counter() - t0
     # ramp the KV context (untimed for the headline, reported as ramp_frames_per_s)
@@ -396,22 +414,29 @@ def main():
         avg_ms = p["train_ms"]
         bytes_per_launch = p["train_bytes"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch from separate --pmc passes (profiles/r01_pmc_attention.json; FETCH_SIZE doubled
-        # per the gfx950 correction).  Measured at B=32, L~4095: only quoted for that workload.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attention.json")))["kernels"]
-            if B == 32 and L == 4096 and not args.layers:
-                traffic = pmc[dom + "<2, false>"]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
-        except Exception:
-            traffic = None
+        # HBM traffic per launch from separate --pmc passes of THIS round's kernels (profiles/r02_pmc_attention.json,
+        # tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950 correction).  Measured at B=32, L~4095: only quoted for
+        # that workload, and only from the file of the round that last touched csrc/attn.hip.
+        traffic, traffic_src = None, None
+        for cand in ("r02_pmc_attention.json",):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
+                if B == 32 and L == 4096 and not args.layers:
+                    traffic = pmc[dom + "<2, false>"]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
+                    traffic_src = "profiles/" + cand
+                    break
+            except Exception:
+                traffic = None
         out = {
             "metric": "audio codec tokens/sec/node (decode, bf16, batch 32 @ 4k ctx)",
             "value": value, "unit": "codec_tokens/s", "n_gpus": world, "ranks": int(nranks.item()),
             "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None, "steps": K, "warmup": W,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights of the ASSUMED 1.7B dims, synthetic prompts)",
-            "config": {"workload": "configs[2]: batch 32 synthetic dialogues/GPU, 4k-token KV context, top-k/top-p sampling on 8 channels, decode steps at full context",
+            "config": {"workload": ("configs[2]: batch 32 synthetic dialogues/GPU, 4k-token KV context, top-k/top-p sampling on 8 channels, decode steps at full context"
+                                    if (B == 32 and L == 4096 and not args.greedy) else
+                                    f"batch {B} synthetic dialogues/GPU, {L}-token KV context, {'greedy' if args.greedy else 'top-k/top-p sampling'} on 8 channels, decode steps at full context"
+                                    + (" (BASELINE configs[1])" if (B == 1 and L == 2048 and args.greedy) else " (not the headline configuration)")),
                        "batch_per_gpu": B, "context": L, "prompt": T, "layers": cfg["num_hidden_layers"],
                        "hidden": cfg["hidden_size"], "parallelism": f"dp{world} (batch shard, no per-step collective)"},
             "frames_per_s": frames, "real_time_factor": frames / 12.5,
@@ -424,7 +449,7 @@ def main():
             "prefill": {"tokens": int(B * n_real), "tokens_per_s": B * n_real / t_prefill,
                         "tflops": 2.0 * stack_params * B * n_real / t_prefill / 1e12, "mfma_peak_tflops": 2500.0},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": 4 * cfg["num_hidden_layers"],
                          "how": "train of back-to-back launches at the end-of-run KV length, 2 HIP events on the launch stream"},
@@ -439,9 +464,12 @@ def main():
         if world == 1 and not args.no_codec:
             if not args.fake_context:
                 out["end_to_end"] = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all)
-                out["end_to_end_overlapped"] = overlapped_leg(cfg, eng, device, ids, mask, T + (L - n_real), layers, 42)
+                if not args.greedy:
+                    out["end_to_end_overlapped"] = overlapped_leg(cfg, eng, device, ids, mask, T + (L - n_real), layers, 42)
             eng.close()
             out["codec_decode"] = codec_leg(device)
+            if not args.no_cpu_baseline:
+                out["codec_decode"]["cpu_baseline"] = codec_cpu_baseline()
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             st_time, per_layer, heads_t = cpu_baseline(cfg, B, L)

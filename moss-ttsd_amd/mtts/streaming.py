@@ -38,7 +38,7 @@ def generate_with_overlapped_decode(engine, codec, input_ids, attention_mask, ma
     main = torch.cuda.default_stream(dev)
     engine.begin(input_ids, attention_mask, max_length, layers=layers, do_samples=do_samples, seed=seed)
     B = engine._B
-    max_steps = int(max_length) - (np.asarray(input_ids).shape[1] - 7)
+    max_steps = int(max_length) - (np.asarray(input_ids).shape[1] - 7) + 14     # + flushes that start at / run past max_length
     done_windows = [dict() for _ in range(B)]          # row -> {window k: wav tensor [<=480000]}
     keep = []                                          # tensors that must outlive the side stream's use
     next_win = 0
