@@ -182,6 +182,20 @@ int32_t mtts_k_gemm_bf16(const void* dev_w, const void* dev_x, void* dev_y,
 /* RMSNorm (Qwen3RMSNorm, modeling_qwen3.py:59-64): x,w bf16 -> y bf16, rows x n. */
 int32_t mtts_k_rmsnorm(const void* dev_x, const void* dev_w, void* dev_y,
                        int32_t rows, int32_t n, float eps, void* stream);
+/* q/k/v epilogue of one new token per row (per-head q/k RMSNorm, RoPE, K/V page write: transformers modeling_qwen3.py
+ * :148-170,251-259): dev_qkv bf16 [R][(nq+2*nkv)*128] = the q|k|v Linear outputs, host_pos int32 [R], norm weights bf16
+ * [128], RoPE tables bf16 [rows][64].  Out (bf16): dev_q [R][nq][128], dev_k / dev_v [R][nkv][128] as read back from the
+ * cache pages they were written to. */
+int32_t mtts_k_rope_kvwrite(const void* dev_qkv, const int32_t* host_pos, const void* dev_qnorm, const void* dev_knorm,
+                            const void* dev_cos, const void* dev_sin, int32_t R, int32_t nq, int32_t nkv, float eps,
+                            void* dev_q, void* dev_k, void* dev_v, void* stream);
+/* Decode attention, one query token per row, over a paged KV cache (eager_attention_forward, modeling_qwen3.py:185-208,
+ * with its three bf16 rounding points): dev_q bf16 [R][nq][128]; dev_k / dev_v bf16 [R][Lmax][nkv][128] (row r holds
+ * host_lens[r] tokens, the query is the last one); host_page_table int32 [R][ceil(Lmax/64)] = any permutation of the
+ * pool's page numbers (NULL: consecutive).  dev_out bf16 [R][nq*128].  R <= 32. */
+int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const void* dev_v, const int32_t* host_lens,
+                                 const int32_t* host_page_table, int32_t R, int32_t Lmax, int32_t nq, int32_t nkv,
+                                 void* dev_out, void* stream);
 /* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
 int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,
                       const void* dev_history_bitmap, const MttsSamplerCfg* cfg,

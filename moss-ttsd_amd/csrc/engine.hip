@@ -1428,6 +1428,105 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     return MTTS_OK;
 }
 
+// ---- per-kernel entry points for attention and RoPE / cache write (unit tests) ----------------------------------------
+void launch_pack_kv_pages(const void* K, const void* V, void* kcache, void* vcache, const int32_t* page_table, const int32_t* lens,
+                          int S, int Lmax, int nkv, int max_pages, int total_pages, hipStream_t st);
+void launch_bf16_to_f32(const void* a, float* b, size_t n, hipStream_t st);
+void launch_unpack_rows(const void* packed, void* out, int R, int K, hipStream_t st);
+
+// q/k/v epilogue of one token per row (qkv_post_kernel): dev_qkv bf16 [R][(nq+2*nkv)*128] = the three Linears' outputs,
+// host_pos int32 [R] positions, dev_qnorm / dev_knorm bf16 [128], dev_cos / dev_sin bf16 [rope_rows][64].
+// Outputs bf16: dev_q [R][nq][128] (normed + rotated), dev_k [R][nkv][128] (normed + rotated, read back from the K page it was
+// written to), dev_v [R][nkv][128] (read back from the V page).  Every row is its own sequence (page table = one page each).
+int32_t mtts_k_rope_kvwrite(const void* dev_qkv, const int32_t* host_pos, const void* dev_qnorm, const void* dev_knorm,
+                            const void* dev_cos, const void* dev_sin, int32_t R, int32_t nq, int32_t nkv, float eps,
+                            void* dev_q, void* dev_k, void* dev_v, void* stream) {
+    if (!dev_qkv || !host_pos || !dev_q || !dev_k || !dev_v || R < 1 || R > MTTS_RCAP || nq < 1 || nkv < 1) return fail(MTTS_EINVAL, "rope_kvwrite: bad argument");
+    hipStream_t st = S(stream);
+    const int N = (nq + 2 * nkv) * MTTS_HD;
+    int maxpos = 0;
+    for (int r = 0; r < R; ++r) { if (host_pos[r] < 0) return fail(MTTS_EINVAL, "negative position"); maxpos = std::max(maxpos, host_pos[r]); }
+    const int max_pages = maxpos / MTTS_PAGE + 1, total_pages = R * max_pages;
+    float* slab = nullptr; RowMeta* meta = nullptr; int32_t* pt = nullptr; uint16_t *kc = nullptr, *vc = nullptr;
+    TRY(dalloc(&slab, (size_t)MTTS_PFCAP * N));
+    TRY(dalloc(&meta, R)); TRY(dalloc(&pt, (size_t)R * max_pages));
+    TRY(dalloc(&kc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD)); TRY(dalloc(&vc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD));
+    std::vector<RowMeta> hm(R);
+    std::vector<int32_t> hpt((size_t)R * max_pages);
+    for (int r = 0; r < R; ++r) { hm[r] = RowMeta{r, host_pos[r], 1, 0}; for (int p = 0; p < max_pages; ++p) hpt[(size_t)r * max_pages + p] = r * max_pages + p; }
+    HIPCHK(hipMemcpy(meta, hm.data(), R * sizeof(RowMeta), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pt, hpt.data(), hpt.size() * 4, hipMemcpyHostToDevice));
+    launch_bf16_to_f32(dev_qkv, slab, (size_t)R * N, st);
+    launch_qkv_post(slab, 1, N, meta, dev_qnorm, dev_knorm, dev_cos, dev_sin, dev_q, kc, vc, pt, max_pages, total_pages, R, nq, nkv, eps, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    // read the written K / V rows back out of their pages
+    std::vector<uint16_t> hk((size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD), hv(hk.size()), ok((size_t)R * nkv * MTTS_HD), ov(ok.size());
+    HIPCHK(hipMemcpy(hk.data(), kc, hk.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hv.data(), vc, hv.size() * 2, hipMemcpyDeviceToHost));
+    for (int r = 0; r < R; ++r)
+        for (int h = 0; h < nkv; ++h)
+            for (int d = 0; d < MTTS_HD; ++d) {
+                const int page = r * max_pages + host_pos[r] / MTTS_PAGE, t = host_pos[r] % MTTS_PAGE;
+                const size_t base = ((size_t)h * total_pages + page) * (MTTS_PAGE * MTTS_HD);
+                ok[((size_t)r * nkv + h) * MTTS_HD + d] = hk[base + (((d >> 3) * 64) + t) * 8 + (d & 7)];
+                ov[((size_t)r * nkv + h) * MTTS_HD + d] = hv[base + ((size_t)(t >> 1) * MTTS_HD + d) * 2 + (t & 1)];
+            }
+    HIPCHK(hipMemcpy(dev_k, ok.data(), ok.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dev_v, ov.data(), ov.size() * 2, hipMemcpyHostToDevice));
+    hipFree(slab); hipFree(meta); hipFree(pt); hipFree(kc); hipFree(vc);
+    return MTTS_OK;
+}
+
+// Decode attention of one query token per row over a paged cache (attn_scores / attn_pv / attn_combine, the launches of
+// a decode step): dev_q bf16 [R][nq][128]; dev_k / dev_v bf16 [R][Lmax][nkv][128] row-major (row r uses its first
+// host_lens[r] tokens; its query sits at position host_lens[r]-1); host_page_table int32 [R][pages] with
+// pages = ceil(Lmax/64): any permutation of 0..R*pages-1 (NULL = consecutive).  dev_out bf16 [R][nq*128].
+int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const void* dev_v, const int32_t* host_lens,
+                                 const int32_t* host_page_table, int32_t R, int32_t Lmax, int32_t nq, int32_t nkv,
+                                 void* dev_out, void* stream) {
+    if (!dev_q || !dev_k || !dev_v || !host_lens || !dev_out || R < 1 || R > MTTS_MAXR || Lmax < 1 || nq < 1 || nkv < 1 || nq % nkv)
+        return fail(MTTS_EINVAL, "paged_attn_decode: bad argument (1..32 rows)");
+    hipStream_t st = S(stream);
+    const int max_pages = (Lmax + MTTS_PAGE - 1) / MTTS_PAGE, total_pages = R * max_pages, nch = (max_pages + ATT_PB - 1) / ATT_PB;
+    std::vector<int32_t> hpt((size_t)R * max_pages);
+    std::vector<char> seen(total_pages, 0);
+    for (size_t i = 0; i < hpt.size(); ++i) {
+        hpt[i] = host_page_table ? host_page_table[i] : (int32_t)i;
+        if (hpt[i] < 0 || hpt[i] >= total_pages || seen[hpt[i]]) return fail(MTTS_EINVAL, "page table must be a permutation of 0..%d", total_pages - 1);
+        seen[hpt[i]] = 1;
+    }
+    std::vector<RowMeta> hm(MTTS_MAXR, RowMeta{-1, 0, 0, 0});
+    int pages_bound = 1;
+    for (int r = 0; r < R; ++r) {
+        if (host_lens[r] < 1 || host_lens[r] > Lmax) return fail(MTTS_EINVAL, "row %d: length %d outside 1..%d", r, host_lens[r], Lmax);
+        hm[r] = RowMeta{r, host_lens[r] - 1, 1, 0};
+        pages_bound = std::max(pages_bound, (host_lens[r] + MTTS_PAGE - 1) / MTTS_PAGE);
+    }
+    RowMeta* meta = nullptr; int32_t *pt = nullptr, *lens = nullptr; uint16_t *kc = nullptr, *vc = nullptr, *scores = nullptr, *outp = nullptr;
+    float *stats = nullptr, *opart = nullptr;
+    const size_t cache_n = (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD;
+    TRY(dalloc(&meta, MTTS_MAXR)); TRY(dalloc(&pt, hpt.size())); TRY(dalloc(&lens, R));
+    TRY(dalloc(&kc, cache_n)); TRY(dalloc(&vc, cache_n));
+    TRY(dalloc(&scores, (size_t)MTTS_MAXR * nq * max_pages * MTTS_PAGE));
+    TRY(dalloc(&stats, (size_t)MTTS_MAXR * nq * max_pages * 2));
+    TRY(dalloc(&opart, (size_t)MTTS_MAXR * nq * nch * MTTS_HD));
+    TRY(dalloc(&outp, (size_t)MTTS_MAXR * nq * MTTS_HD));
+    HIPCHK(hipMemcpy(meta, hm.data(), hm.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pt, hpt.data(), hpt.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(lens, host_lens, R * 4, hipMemcpyHostToDevice));
+    launch_pack_kv_pages(dev_k, dev_v, kc, vc, pt, lens, R, Lmax, nkv, max_pages, total_pages, st);
+    const float scale = 1.0f / sqrtf((float)MTTS_HD);
+    if (launch_attn(dev_q, kc, vc, pt, meta, scores, stats, opart, outp, MTTS_MAXR, pages_bound, max_pages, total_pages, nch, nq, nkv,
+                    scale, nullptr, 0, st))
+        return fail(MTTS_EINVAL, "attention group size not built (1, 2, 4)");
+    launch_unpack_rows(outp, dev_out, R, nq * MTTS_HD, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(meta); hipFree(pt); hipFree(lens); hipFree(kc); hipFree(vc); hipFree(scores); hipFree(stats); hipFree(opart); hipFree(outp);
+    return MTTS_OK;
+}
+
 // Measurement hook (bench/profiling only): pretend every live sequence already holds `kv_len` tokens.
 // The cache content is whatever the pages hold; used to reach a long context without replaying it
 // when collecting PMC counters.

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 enum { EPI_SILU_RM = 3 };      // SwiGLU, row-major bf16 [rows][N/2] output
 
 template <int WAVES, int EPI, int PRO>
-__global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
+__global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
     const u32x4_t* __restrict__ Wp, int KT, int kt_per_split, int kt_per_wave, float* __restrict__ partial,
     uint16_t* __restrict__ out, int Npad, int n_valid, SmallPro pr) {
     __shared__ float red[WAVES][16][64];
@@ -133,12 +133,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
     const u32x4_t* wp = Wp + ((size_t)nt * KT + kt0) * 64 + lane;
     // the first weight tiles go out before the prologue: its round trips overlap theirs
     u32x4_t a[U];
-    if (n >= U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
-    }
+    for (int u = 0; u < U; ++u)
+        if (u < n) a[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
     const int kt_base = (PRO == PRO_NORM) ? 0 : kb0;
     if (PRO == PRO_NORM) {
+        // Two passes over the row with x' parked (as bf16, exactly what the residual stream stores) in the LDS slot
+        // that will hold xn: nothing but the running sum of squares lives in registers across the block-wide sum, so
+        // the kernel keeps two 512-thread blocks per CU (a register-resident row cost 200 VGPRs = one block).
         const int H = KT * 16;
         constexpr int G = WAVES / 4;                                   // rows handled at a time (256 threads each)
         const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
@@ -147,52 +149,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
         for (int r0 = 0; r0 < pr.rows; r0 += G) {
             const int r = r0 + g;
             const bool act = r < pr.rows;
-            constexpr int MAXC = 4;                                    // H <= 8192
-            float v[MAXC][8];
-            u32x4_t nw[MAXC];
             float ss = 0.f;
+#pragma unroll 1
+            for (int i0 = t * 8; i0 < H; i0 += 2048) {
+                if (!act) break;
+                const u32x4_t xo = *(const u32x4_t*)(pr.x_in + (size_t)r * H + i0);
+                float v[8];
+                if (pr.ksplit > 0) {
+                    const float* p0 = pr.slabs + (size_t)r * pr.slab_npad + i0;
+                    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+                    for (int k0 = 0; k0 < pr.ksplit; k0 += 4) {        // slabs summed in the fixed order k = 0, 1, 2, ...
+                        float4 ta[4], tb[4];
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int i0 = c * 2048 + t * 8;
-                if (i0 < H && act) {
-                    const u32x4_t xo = *(const u32x4_t*)(pr.x_in + (size_t)r * H + i0);
-                    nw[c] = *(const u32x4_t*)(pr.norm_w + i0);
-                    if (pr.ksplit > 0) {
-                        const float* p0 = pr.slabs + (size_t)r * pr.slab_npad + i0;
-                        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-                        for (int k0 = 0; k0 < pr.ksplit; k0 += 8) {
-                            float4 ta[8], tb[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float* pk = p0 + (size_t)min(k0 + j, pr.ksplit - 1) * kstride;
-                                ta[j] = *(const float4*)pk;
-                                tb[j] = *(const float4*)(pk + 4);
-                            }
-                            if (k0 == 0) { sa = ta[0]; sb = tb[0]; }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (k0 + j < pr.ksplit && k0 + j > 0) {
-                                    sa.x += ta[j].x; sa.y += ta[j].y; sa.z += ta[j].z; sa.w += ta[j].w;
-                                    sb.x += tb[j].x; sb.y += tb[j].y; sb.z += tb[j].z; sb.w += tb[j].w;
-                                }
+                        for (int j = 0; j < 4; ++j) {
+                            const float* pk = p0 + (size_t)min(k0 + j, pr.ksplit - 1) * kstride;
+                            ta[j] = *(const float4*)pk;
+                            tb[j] = *(const float4*)(pk + 4);
                         }
-                        v[c][0] = rbf(bflo(xo.x) + rbf(sa.x)); v[c][1] = rbf(bfhi(xo.x) + rbf(sa.y));
-                        v[c][2] = rbf(bflo(xo.y) + rbf(sa.z)); v[c][3] = rbf(bfhi(xo.y) + rbf(sa.w));
-                        v[c][4] = rbf(bflo(xo.z) + rbf(sb.x)); v[c][5] = rbf(bfhi(xo.z) + rbf(sb.y));
-                        v[c][6] = rbf(bflo(xo.w) + rbf(sb.z)); v[c][7] = rbf(bfhi(xo.w) + rbf(sb.w));
-                    } else {                                           // first layer: x is the embedding sum itself
-                        v[c][0] = bflo(xo.x); v[c][1] = bfhi(xo.x); v[c][2] = bflo(xo.y); v[c][3] = bfhi(xo.y);
-                        v[c][4] = bflo(xo.z); v[c][5] = bfhi(xo.z); v[c][6] = bflo(xo.w); v[c][7] = bfhi(xo.w);
-                    }
-                    if (writer) {
-                        u32x4_t xn;
-                        xn.x = pack2(v[c][0], v[c][1]); xn.y = pack2(v[c][2], v[c][3]);
-                        xn.z = pack2(v[c][4], v[c][5]); xn.w = pack2(v[c][6], v[c][7]);
-                        *(u32x4_t*)(pr.x_out + (size_t)r * H + i0) = xn;
-                    }
+                        if (k0 == 0) { sa = ta[0]; sb = tb[0]; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + j < pr.ksplit && k0 + j > 0) {
+                                sa.x += ta[j].x; sa.y += ta[j].y; sa.z += ta[j].z; sa.w += ta[j].w;
+                                sb.x += tb[j].x; sb.y += tb[j].y; sb.z += tb[j].z; sb.w += tb[j].w;
+                            }
+                    }
+                    v[0] = rbf(bflo(xo.x) + rbf(sa.x)); v[1] = rbf(bfhi(xo.x) + rbf(sa.y));
+                    v[2] = rbf(bflo(xo.y) + rbf(sa.z)); v[3] = rbf(bfhi(xo.y) + rbf(sa.w));
+                    v[4] = rbf(bflo(xo.z) + rbf(sb.x)); v[5] = rbf(bfhi(xo.z) + rbf(sb.y));
+                    v[6] = rbf(bflo(xo.w) + rbf(sb.z)); v[7] = rbf(bfhi(xo.w) + rbf(sb.w));
+                } else {                                               // first layer: x is the embedding sum itself
+                    v[0] = bflo(xo.x); v[1] = bfhi(xo.x); v[2] = bflo(xo.y); v[3] = bfhi(xo.y);
+                    v[4] = bflo(xo.z); v[5] = bfhi(xo.z); v[6] = bflo(xo.w); v[7] = bfhi(xo.w);
                 }
+                u32x4_t xn;
+                xn.x = pack2(v[0], v[1]); xn.y = pack2(v[2], v[3]); xn.z = pack2(v[4], v[5]); xn.w = pack2(v[6], v[7]);
+                if (writer) *(u32x4_t*)(pr.x_out + (size_t)r * H + i0) = xn;
+                xs[(size_t)(i0 >> 3) * SMALL_RP + r] = xn;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
             }
             // block_sum_256 of resid_norm_kernel, per group of 256 threads
             ss = wave_sum(ss);
@@ -201,18 +196,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
             const float tot = sh[g][0] + sh[g][1] + sh[g][2] + sh[g][3];
             __syncthreads();
             const float inv = 1.0f / sqrtf(tot / (float)H + pr.eps);
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int i0 = c * 2048 + t * 8;
-                if (i0 < H && act) {
-                    const u32x4_t w = nw[c];
-                    u32x4_t y;
-                    y.x = pack2(bflo(w.x) * rbf(v[c][0] * inv), bfhi(w.x) * rbf(v[c][1] * inv));
-                    y.y = pack2(bflo(w.y) * rbf(v[c][2] * inv), bfhi(w.y) * rbf(v[c][3] * inv));
-                    y.z = pack2(bflo(w.z) * rbf(v[c][4] * inv), bfhi(w.z) * rbf(v[c][5] * inv));
-                    y.w = pack2(bflo(w.w) * rbf(v[c][6] * inv), bfhi(w.w) * rbf(v[c][7] * inv));
-                    xs[(size_t)(i0 >> 3) * SMALL_RP + r] = y;
-                }
+#pragma unroll 1
+            for (int i0 = t * 8; i0 < H; i0 += 2048) {
+                if (!act) break;
+                const u32x4_t w = *(const u32x4_t*)(pr.norm_w + i0);
+                const u32x4_t xv = xs[(size_t)(i0 >> 3) * SMALL_RP + r];
+                u32x4_t y;
+                y.x = pack2(bflo(w.x) * rbf(bflo(xv.x) * inv), bfhi(w.x) * rbf(bfhi(xv.x) * inv));
+                y.y = pack2(bflo(w.y) * rbf(bflo(xv.y) * inv), bfhi(w.y) * rbf(bfhi(xv.y) * inv));
+                y.z = pack2(bflo(w.z) * rbf(bflo(xv.z) * inv), bfhi(w.z) * rbf(bfhi(xv.z) * inv));
+                y.w = pack2(bflo(w.w) * rbf(bflo(xv.w) * inv), bfhi(w.w) * rbf(bfhi(xv.w) * inv));
+                xs[(size_t)(i0 >> 3) * SMALL_RP + r] = y;
             }
         }
     } else if (PRO == PRO_COMBINE) {
@@ -253,12 +247,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_small_kernel(
     const u32x4_t zero = {0u, 0u, 0u, 0u};
     // lane's B fragment of k-tile kt: 16-byte group (kt - kt_base)*2 + (lane >> 5), its row
     const u32x4_t* xl = xs + (size_t)((kt0 - kt_base) * 2 + (lane >> 5)) * SMALL_RP + (has ? row : 0);
-    int i = 0;
-    for (; i + U <= n; i += U) {
-        if (i > 0) {
+    // the tiles fetched before the prologue (all of them for the shapes whose waves own <= 8)
 #pragma unroll
-            for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
+    for (int u = 0; u < U; ++u)
+        if (u < n) {
+            const u32x4_t t = xl[(size_t)u * 2 * SMALL_RP];
+            const u32x4_t bw = has ? t : zero;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&a[u], *(bf16x8_t*)&bw, acc, 0, 0, 0);
         }
+    int i = U;
+    for (; i + U <= n; i += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(wp + (size_t)(i + u) * 64);
         u32x4_t b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {

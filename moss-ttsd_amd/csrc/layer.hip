@@ -297,3 +297,41 @@ __global__ void set_pages_kernel(int32_t* __restrict__ table, PageEdits ed) {
 void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st) {
     hipLaunchKernelGGL(set_pages_kernel, dim3(1), dim3(64), 0, st, table, ed);
 }
+
+// Unit-test helper (mtts_k_paged_attn_decode): row-major K / V [seq][Lmax][nkv][128] bf16 -> the paged cache layouts
+// (K page [d/8][token][8], V page [token pair][d][2]) through an arbitrary page table.
+__global__ void pack_kv_pages_kernel(const uint16_t* __restrict__ K, const uint16_t* __restrict__ V, uint16_t* __restrict__ kcache,
+                                     uint16_t* __restrict__ vcache, const int32_t* __restrict__ page_table, const int32_t* __restrict__ lens,
+                                     int Lmax, int nkv, int max_pages, int total_pages) {
+    const int seq = blockIdx.z, kvh = blockIdx.y, tok = blockIdx.x, d = threadIdx.x;
+    if (tok >= lens[seq]) return;
+    const int page = page_table[(size_t)seq * max_pages + (tok >> 6)], t = tok & 63;
+    const size_t src = (((size_t)seq * Lmax + tok) * nkv + kvh) * MTTS_HD + d;
+    const size_t base = ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD);
+    kcache[base + (((d >> 3) * 64) + t) * 8 + (d & 7)] = K[src];
+    vcache[base + ((size_t)(t >> 1) * MTTS_HD + d) * 2 + (t & 1)] = V[src];
+}
+void launch_pack_kv_pages(const void* K, const void* V, void* kcache, void* vcache, const int32_t* page_table, const int32_t* lens,
+                          int S, int Lmax, int nkv, int max_pages, int total_pages, hipStream_t st) {
+    hipLaunchKernelGGL(pack_kv_pages_kernel, dim3(Lmax, nkv, S), dim3(MTTS_HD), 0, st, (const uint16_t*)K, (const uint16_t*)V,
+                       (uint16_t*)kcache, (uint16_t*)vcache, page_table, lens, Lmax, nkv, max_pages, total_pages);
+}
+// bf16 [n] -> fp32 [n] (exact): lets the unit-test entry points feed bf16 Linear outputs to kernels that read fp32 slabs
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ a, float* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = bf2f(a[i]);
+}
+void launch_bf16_to_f32(const void* a, float* b, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint16_t*)a, b, n);
+}
+// X-fragment layout [rows/32 tiles][K/16][lane][8] -> row-major [R][K]
+__global__ void unpack_rows_kernel(const uint16_t* __restrict__ packed, uint16_t* __restrict__ out, int R, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    out[i] = packed[xpack_off(r, k, K)];
+}
+void launch_unpack_rows(const void* packed, void* out, int R, int K, hipStream_t st) {
+    const size_t n = (size_t)R * K;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint16_t*)packed, (uint16_t*)out, R, K);
+}

@@ -80,6 +80,8 @@ _SIGS = {
     "mtts_k_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     "mtts_k_rmsnorm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "mtts_k_rope_kvwrite": (C.c_int32, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 4),
+    "mtts_k_paged_attn_decode": (C.c_int32, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
     "mtts_k_sample": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(MttsSamplerCfg),
                                   C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mtts_codec_last_error": (C.c_char_p, []),

@@ -634,3 +634,83 @@ def test_fp32_engine_long_run_equals_fp32_oracle():
         n = min(upto, gold.shape[1], out.shape[1])
         assert n >= ids.shape[1] - 7 + steps // 2
         assert np.array_equal(out[:, :n], gold[:, :n]), B
+
+
+def test_rope_kvwrite_kernel_bit_exact_vs_oracle():
+    """mtts_k_rope_kvwrite = the q/k/v epilogue of a decode / prefill row on its own (qkv_post_kernel): per-head q/k
+    RMSNorm, RoPE in bf16 with its three roundings (modeling_qwen3.py:148-170,251-252), K and V written into their
+    cache pages (and read back from them).  Against the oracle's rmsnorm / apply_rope: every bit."""
+    from mtts.engine import rope_tables
+    lib = capi.lib()
+    rng = np.random.default_rng(5)
+    cfg = synth.tiny()
+    orc = ao.AsteroidOracle(cfg, {}, "bf16")
+    for R, nq, nkv in ((7, 4, 2), (32, 16, 8), (3, 2, 2)):
+        N = (nq + 2 * nkv) * 128
+        qkv = ao.round_bf16(rng.standard_normal((R, N)).astype(np.float32) * 2)
+        pos = rng.integers(0, 700, R).astype(np.int32)
+        qn = ao.round_bf16(1 + 0.2 * rng.standard_normal(128).astype(np.float32))
+        kn = ao.round_bf16(1 + 0.2 * rng.standard_normal(128).astype(np.float32))
+        cos, sin = rope_tables(128, float(cfg["rope_theta"]), 704, "cuda")
+        q = torch.zeros(R, nq, 128, dtype=torch.bfloat16, device="cuda")
+        k = torch.zeros(R, nkv, 128, dtype=torch.bfloat16, device="cuda")
+        v = torch.zeros(R, nkv, 128, dtype=torch.bfloat16, device="cuda")
+        qt, qnt, knt = _bf16_t(qkv), _bf16_t(qn), _bf16_t(kn)
+        capi.check(lib.mtts_k_rope_kvwrite(qt.data_ptr(), pos.ctypes.data, qnt.data_ptr(), knt.data_ptr(), cos.data_ptr(),
+                                           sin.data_ptr(), R, nq, nkv, C.c_float(1e-6), q.data_ptr(), k.data_ptr(), v.data_ptr(), None))
+        torch.cuda.synchronize()
+        oc, os_ = orc.rope(pos[:, None].astype(np.int64))                  # [R,1,128]
+        qh = qkv[:, :nq * 128].reshape(R, 1, nq, 128)
+        kh = qkv[:, nq * 128:(nq + nkv) * 128].reshape(R, 1, nkv, 128)
+        want_q = orc.apply_rope(orc.rmsnorm(qh, qn).transpose(0, 2, 1, 3), oc, os_)[:, :, 0]
+        want_k = orc.apply_rope(orc.rmsnorm(kh, kn).transpose(0, 2, 1, 3), oc, os_)[:, :, 0]
+        want_v = qkv[:, (nq + nkv) * 128:].reshape(R, nkv, 128)
+        assert np.array_equal(q.float().cpu().numpy(), want_q)
+        assert np.array_equal(k.float().cpu().numpy(), want_k)
+        assert np.array_equal(v.float().cpu().numpy(), want_v)
+
+
+@pytest.mark.parametrize("nq,nkv", [(4, 2), (4, 4), (8, 2)])
+def test_paged_attn_decode_kernel_vs_oracle(nq, nkv):
+    """mtts_k_paged_attn_decode = the three attention launches of a decode step on their own (scores, P.V, combine)
+    over a paged cache with a SHUFFLED page table, ragged lengths 1..1500 (24 pages, 3 pass-B chunks).  Against the
+    eager formula with the reference's rounding points (s = bf16(bf16(q.k) * scale), p = bf16(softmax_fp32(s)),
+    o = bf16(p.V), modeling_qwen3.py:185-208): fp32 summation order is the only freedom, so nearly every bf16 output is
+    bit-identical and the rest is one ulp away."""
+    lib = capi.lib()
+    rng = np.random.default_rng(11 + nq + nkv)
+    R, Lmax = 6, 1500
+    lens = np.array([1500, 1, 64, 65, 777, 1023], dtype=np.int32)
+    q = ao.round_bf16(rng.standard_normal((R, nq, 128)).astype(np.float32))
+    K = ao.round_bf16(rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32))
+    V = ao.round_bf16(rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32))
+    pages = (Lmax + 63) // 64
+    table = rng.permutation(R * pages).astype(np.int32).reshape(R, pages)
+    out = torch.zeros(R, nq * 128, dtype=torch.bfloat16, device="cuda")
+    qt, kt, vt = _bf16_t(q), _bf16_t(K), _bf16_t(V)
+    capi.check(lib.mtts_k_paged_attn_decode(qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), lens.ctypes.data, table.ctypes.data,
+                                            R, Lmax, nq, nkv, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy().reshape(R, nq, 128)
+    g = nq // nkv
+    scale = np.float32(128 ** -0.5)
+    exact = total = 0
+    for r in range(R):
+        n = int(lens[r])
+        Kr = np.repeat(K[r, :n].transpose(1, 0, 2), g, axis=0)            # [nq, n, 128]
+        Vr = np.repeat(V[r, :n].transpose(1, 0, 2), g, axis=0)
+        s = ao.round_bf16(np.einsum("hd,hnd->hn", q[r], Kr).astype(np.float32))
+        s = ao.round_bf16(s * scale)
+        p = ao.round_bf16(ao.softmax_f32(s))
+        o = ao.round_bf16(np.einsum("hn,hnd->hd", p, Vr).astype(np.float32))
+        tol = 2.0 ** -7 * np.abs(o).max()
+        assert np.abs(got[r] - o).max() <= tol, (r, float(np.abs(got[r] - o).max()), float(tol))
+        exact += int((got[r] == o).sum())
+        total += o.size
+    assert exact >= 0.9 * total, (exact, total)
+    # the same through consecutive pages: identical bits (the table only redirects)
+    out2 = torch.zeros_like(out)
+    capi.check(lib.mtts_k_paged_attn_decode(qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), lens.ctypes.data, None,
+                                            R, Lmax, nq, nkv, out2.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
