@@ -1,6 +1,8 @@
 """Agreement of the HIP engine with the reference's greedy runs over ALL decisions (no margin gate), per fixture.
 and the codec decoder's waveform error against the reference's fixtures.  GPU box only.
-Writes gpurun_out/r01_parity_stats.json and gpurun_out/r01_codec_parity_stats.json (copied to profiles/)."""
+Writes gpurun_out/r02_parity_stats.json and gpurun_out/r02_codec_parity_stats.json (copied to profiles/).
+Every decision where the engine differs from the reference is listed with the two candidates' logits as the engine and
+as the oracle (which agrees with the reference there or not) computed them."""
 import json, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "moss-ttsd_amd")); sys.path.insert(0, ROOT)
@@ -10,7 +12,7 @@ from mtts.engine import Engine
 from oracle import asteroid_oracle as ao
 
 out = {}
-for name in ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty"]:
+for name in ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty", "ar_flush_past_max"]:
     z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     cfg = json.loads(str(z["cfg"]))
     w = synth.synth_weights(cfg, int(z["seed"]), **json.loads(str(z["wkw"])))
@@ -33,12 +35,32 @@ for name in ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_
         "hip_equals_oracle": int((dec[used] == odec[used]).sum()),
         "exact_ties_in_reference": int((used & (m == 0)).sum()),
     }
+    # anatomy of every miss: replay to that step with the step API and read the engine's logits of the two candidates
+    misses = np.argwhere(used & (dec != want))
+    out[name]["misses"] = []
+    if len(misses):
+        _, _, ologs = orc.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers, forced=gold, return_logits=True)
+        for (s_, b_, c_) in misses:
+            # the logits that decide step s_ are those left by the forward of step s_-1: replay exactly s_ forced steps
+            if int(s_) == 0:
+                eng.begin(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers)
+            else:
+                eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers, forced=gold[:, :T - 7 + int(s_)])
+            l0, l17 = eng.read_logits()
+            hl = (l0 if c_ == 0 else l17[c_ - 1])[b_]
+            ol = ologs[int(s_)][int(c_)][b_]
+            a, h = int(want[s_, b_, c_]), int(dec[s_, b_, c_])
+            out[name]["misses"].append({"step": int(s_), "row": int(b_), "channel": int(c_), "reference_token": a, "hip_token": h,
+                                        "reference_margin": float(m[s_, b_, c_]),
+                                        "hip_logits(ref_tok,hip_tok)": [float(hl[a]), float(hl[h])],
+                                        "oracle_logits(ref_tok,hip_tok)": [float(ol[a]), float(ol[h])],
+                                        "oracle_token": int(odec[s_, b_, c_])})
     eng.close()
     print(name, out[name], flush=True)
-tot = {k: sum(v[k] for v in out.values()) for k in next(iter(out.values()))}
+tot = {k: sum(v[k] for v in out.values()) for k in next(iter(out.values())) if k != "misses"}
 out["total"] = tot
 print("total", tot)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r01_parity_stats.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_parity_stats.json"), "w"), indent=1)
 
 # ---- codec decoder: waveform RMS error against the reference's fixtures, both GEMM modes ------------------------
 import torch
@@ -65,4 +87,4 @@ for mode in ("bf16x3", "f32"):
             sig.append(float(np.sqrt(np.mean(ref ** 2))))
         codec.setdefault(name, {})[mode] = {"max_rms_error": max(errs), "signal_rms": max(sig)}
         print(name, mode, codec[name][mode])
-json.dump(codec, open(os.path.join(ROOT, "gpurun_out", "r01_codec_parity_stats.json"), "w"), indent=1)
+json.dump(codec, open(os.path.join(ROOT, "gpurun_out", "r02_codec_parity_stats.json"), "w"), indent=1)
