@@ -41,11 +41,34 @@ struct GemmF32Args {
     int act;               // 0 none, 1 GELU (erf)
     int batch_inner;       // z -> (zo = z / batch_inner, zi = z % batch_inner)
     long sAo, sAi, sWo, sWi, sCo, sCi;
+    // pre-split operands / output (gemm_b3t_kernel): bf16 hi and lo planes in MFMA-fragment order (common.h xpack_off / wpack_off)
+    const uint16_t *Ahi, *Alo, *Whi, *Wlo;
+    uint16_t *Chi, *Clo;
 };
 
 #define GT 128
 #define GK 16
 #define GLD (GT + 4)
+
+__constant__ int g_xcd_map = 1;      // MTTS_CODEC_XCD=0 switches the mapping below off (A/B measurements)
+// XCD-aware block -> tile mapping for the 128 x 128-tile GEMMs.  Workgroups are dealt round-robin over the 8 XCDs (each
+// with its own 4 MiB L2), so with the plain (blockIdx.x, blockIdx.y) order the ~64 blocks resident on one XCD work on
+// tiles scattered over the whole output: every operand tile is pulled through 8 different L2s and the GEMM ends up bound
+// by Infinity-Cache traffic (measured: 3.1 GB of operand fetches for a 24 000 x 4096 x 512 product = 5 TB/s, i.e. the
+// 32 flop/B of a 128^2 fp32 tile, not the matrix cores).  Here XCD x = (linear id % 8) walks its own contiguous share
+// of the tiles in an order where consecutive tiles form panels of 8 tile-rows (M) swept along N: the blocks resident on
+// an XCD at any time cover ~8 x 8 tiles and share their operand rows in that XCD's L2.  Bijective for any grid.
+__device__ __forceinline__ void xcd_tile(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int T = tiles_m * tiles_n, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int x = L & 7, sidx = L >> 3, q = T >> 3, r = T & 7;
+    const int gidx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sidx;      // position in the panel-major order
+    constexpr int SM = 8;
+    const int p = gidx / (SM * tiles_n);
+    const int rows = min(SM, tiles_m - p * SM);
+    const int idx = gidx - p * SM * tiles_n;
+    tn = idx / rows;
+    tm = p * SM + idx % rows;
+}
 
 template <bool B_KN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
@@ -56,7 +79,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
     const float* A = g.A + zo * g.sAo + zi * g.sAi;
     const float* W = g.W + zo * g.sWo + zi * g.sWi;
     float* C = g.C + zo * g.sCo + zi * g.sCi;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    int tm_ = blockIdx.y, tn_ = blockIdx.x;
+    if (gridDim.z == 1 && g_xcd_map) xcd_tile((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, tm_, tn_);
+    const int m0 = tm_ * GT, n0 = tn_ * GT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     f32x16_t acc[2][2];
@@ -207,7 +232,9 @@ __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(GemmF32Args g) {
     const float* A = g.A + zo * g.sAo + zi * g.sAi;
     const float* W = g.W + zo * g.sWo + zi * g.sWi;
     float* C = g.C + zo * g.sCo + zi * g.sCi;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * BN;
+    int tm_ = blockIdx.y, tn_ = blockIdx.x;
+    if (gridDim.z == 1 && g_xcd_map && BN == GT) xcd_tile((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, tm_, tn_);
+    const int m0 = tm_ * GT, n0 = tn_ * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     f32x16_t acc[2][NJ];
@@ -320,6 +347,128 @@ __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(GemmF32Args g) {
         }
 }
 
+__device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
+    uint32_t h, l;
+    split2(x, 0.f, h, l);
+    hi = (uint16_t)h;
+    lo = (uint16_t)l;
+}
+
+// ------------------------------------------------------------------------------------
+// bf16x3 GEMM on pre-split operands in MFMA-FRAGMENT ORDER, no LDS (the layout of the AR engine's GEMMs, common.h):
+//   activations  [row/32][k/16][lane][8 bf16], lane = row%32 + 32*((k%16)/8)     (xpack_off; hi plane, then lo plane)
+//   weights      [n/32][k/16][lane][8 bf16],   lane = n%32 + 32*((k%16)/8)       (wpack_off; split + packed once)
+// so every operand fragment of a wave is ONE contiguous KiB straight into registers.  What bounded the LDS-staged
+// kernels was bytes in flight (two blocks x 32 KB of LDS stage per CU against ~1.5 us of loaded L2 latency: SQ_WAIT_ANY
+// 43 %, matrix cores 31 % busy, no bank conflicts, 88 % L2 hits); registers hold 4 k-steps x 8 fragments = 32 KiB per WAVE
+// in flight.  Block = 128 x 128 outputs, 4 waves (2 x 2), a wave = 64 columns x 64 rows = 2 x 2 accumulators D[n][row];
+// per 16-deep step 8 fragment loads and 12 MFMAs (w_hi*x_lo, w_lo*x_hi, w_hi*x_hi: the products of gemm_b3_kernel).
+// Output: fp32 C (bias / GELU / gamma / residual, float4 per lane) or fragment-packed hi / lo planes for the next GEMM.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_b3t_kernel(GemmF32Args g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ntiles = (g.N + 31) / 32, rtiles = (g.M + 31) / 32, KT = g.K / 16;
+    int tm_ = blockIdx.y, tn_ = blockIdx.x;
+    if (g_xcd_map) xcd_tile((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, tm_, tn_);
+    const int nt0 = tn_ * 4 + (wave & 1) * 2, rt0 = tm_ * 4 + (wave >> 1) * 2;
+    if (nt0 >= ntiles || rt0 >= rtiles) return;
+    const bool n1 = nt0 + 1 < ntiles, r1 = rt0 + 1 < rtiles;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const size_t xtile = (size_t)KT * 64;                    // one 32-row / 32-column tile, in 16-byte units
+    const u32x4_t* wh[2] = {(const u32x4_t*)g.Whi + (size_t)nt0 * xtile + lane, (const u32x4_t*)g.Whi + (size_t)(n1 ? nt0 + 1 : nt0) * xtile + lane};
+    const u32x4_t* wl[2] = {(const u32x4_t*)g.Wlo + (size_t)nt0 * xtile + lane, (const u32x4_t*)g.Wlo + (size_t)(n1 ? nt0 + 1 : nt0) * xtile + lane};
+    const u32x4_t* xh[2] = {(const u32x4_t*)g.Ahi + (size_t)rt0 * xtile + lane, (const u32x4_t*)g.Ahi + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + lane};
+    const u32x4_t* xl[2] = {(const u32x4_t*)g.Alo + (size_t)rt0 * xtile + lane, (const u32x4_t*)g.Alo + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + lane};
+    // Two register sets of U k-steps each, ping-pong: the loads of one set are issued before the MFMAs of the other and
+    // the scheduler is kept from interleaving them back into short-distance load/use pairs (sched_barrier): while a set
+    // of 8 U fragments feeds the matrix cores the other 8 U KiB per wave are in flight.
+    constexpr int U = 2;
+    struct FragSet { u32x4_t ah[2][U], al[2][U], bh[2][U], bl[2][U]; };
+    auto load = [&](FragSet& f, int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f.ah[t][u] = wh[t][(size_t)(i0 + u) * 64]; f.al[t][u] = wl[t][(size_t)(i0 + u) * 64];
+                f.bh[t][u] = xh[t][(size_t)(i0 + u) * 64]; f.bl[t][u] = xl[t][(size_t)(i0 + u) * 64];
+            }
+    };
+    auto compute = [&](FragSet& f) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.ah[a][u], *(bf16x8_t*)&f.bl[b][u], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.al[a][u], *(bf16x8_t*)&f.bh[b][u], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.ah[a][u], *(bf16x8_t*)&f.bh[b][u], acc[a][b], 0, 0, 0);
+                }
+    };
+    FragSet fa, fb;                                  // KT is a multiple of 2 U on this path (gemm_planes checks)
+    load(fa, 0);
+    for (int i = 0; i < KT; i += 2 * U) {
+        load(fb, i + U);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        load(fa, min(i + 2 * U, KT - U));              // (the last round re-reads its own tiles: no branch, so the
+                                                       //  waits stay counted instead of falling back to vmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // D[n][row]: lane holds row = lane & 31 and n = 8q + 4(lane>>5) + j (register 4q + j)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a && !n1) break;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b && !r1) break;
+            const int m = (rt0 + b) * 32 + (lane & 31);
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = (nt0 + a) * 32 + 8 * q + 4 * (lane >> 5);
+                if (n >= g.N) continue;                    // N is a multiple of 4 on this path
+                float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                if (g.bias) { const float4 t = *(const float4*)(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                if (g.act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+                }
+                if (g.gamma) { const float4 t = *(const float4*)(g.gamma + n); v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w; }
+                if (g.res) { const float4 t = *(const float4*)(g.res + (long)m * g.ldres + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                if (g.Chi) {
+                    uint32_t h0, l0, h1, l1;
+                    split2(v[0], v[1], h0, l0);
+                    split2(v[2], v[3], h1, l1);
+                    const size_t at = xpack_off(m, n, (int)g.ldc);
+                    *(u32x2_t*)(g.Chi + at) = u32x2_t{h0, h1};
+                    *(u32x2_t*)(g.Clo + at) = u32x2_t{l0, l1};
+                } else {
+                    *(float4*)(g.C + (long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+// fp32 weight [N][K] -> fragment-packed bf16 hi / lo planes (padding rows of the last 32-column tile stay zero)
+__global__ void split_pack_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int N, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const size_t at = wpack_off(n, k, K / 16);
+    split1(w[i], hi[at], lo[at]);
+}
+
 // 0 = exact f32 MFMA everywhere, 1 = bf16x3 for the [N][K]-weight GEMMs (set per call path: decode 1, encode 0)
 static thread_local int g_gemm_split = 0;
 
@@ -329,7 +478,7 @@ static void gemm_f32(hipStream_t st, bool b_kn, const float* A, const float* W, 
                      int batch_inner = 1, long sAo = 0, long sAi = 0, long sWo = 0, long sWi = 0, long sCo = 0,
                      long sCi = 0) {
     GemmF32Args g{A, W, C, bias, gamma, res, M, N, K, lda, ldw, ldc, ldres, res_rows, scale, act, batch_inner,
-                  sAo, sAi, sWo, sWi, sCo, sCi};
+                  sAo, sAi, sWo, sWi, sCo, sCi, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
     // [K][N] weights (P.V of the codec attention, the inverse-DFT basis) are bound by their operand traffic, not by
     // the matrix cores (measured: 430 vs 442 us as bf16x3): they keep the exact kernel
@@ -377,7 +526,9 @@ __global__ void add_pe_kernel(float* x, const float* pe, long n, int T, int d) {
 // when lens != null (torch.where(attention_mask, h, 0), modules.py:409,626).
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows, int C,
-                                                        float eps, const int* __restrict__ lens, int T, long ldy) {
+                                                        float eps, const int* __restrict__ lens, int T, long ldy,
+                                                        uint16_t* __restrict__ ylo = nullptr) {
+    // ylo != null: the output feeds a pre-split GEMM only -- write bf16 hi / lo planes (hi plane at `y`) instead of fp32
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * C;
@@ -394,7 +545,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) y[(long)row * ldy + c] = zero ? 0.f : (v[i] - mu) * inv * w[c] + b[c];
+        if (c < C) {
+            const float o = zero ? 0.f : (v[i] - mu) * inv * w[c] + b[c];
+            if (ylo) { const size_t at = xpack_off(row, c, (int)ldy); split1(o, ((uint16_t*)y)[at], ylo[at]); }
+            else y[(long)row * ldy + c] = o;
+        }
     }
 }
 
@@ -533,7 +688,7 @@ __global__ void im2col7_kernel(const float* __restrict__ x, float* __restrict__ 
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ h, const float* __restrict__ dw,
                                                         const float* __restrict__ dwb, const float* __restrict__ lw,
                                                         const float* __restrict__ lb, float* __restrict__ y, int B, int T,
-                                                        int C, float eps) {
+                                                        int C, float eps, uint16_t* __restrict__ ylo = nullptr) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= (long)B * T) return;
@@ -563,7 +718,11 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) y[row * C + c] = (v[i] - mu) * inv * lw[c] + lb[c];
+        if (c < C) {
+            const float o = (v[i] - mu) * inv * lw[c] + lb[c];
+            if (ylo) { const size_t at = xpack_off((int)row, c, C); split1(o, ((uint16_t*)y)[at], ylo[at]); }
+            else y[row * C + c] = o;
+        }
     }
 }
 // ISTFT head front (modules.py:970-985): o[.., :nb] = log-magnitude, o[.., nb:] = phase
@@ -745,6 +904,9 @@ struct MttsCodec {
     int64_t* d_codes = nullptr;
     int *d_lens = nullptr, *d_lens4 = nullptr, *d_err = nullptr;
     int split_decode = 1;       // decode-direction GEMMs as bf16x3 (MTTS_CODEC_GEMM=f32: exact f32 MFMA)
+    // bf16 hi/lo planes of the constant weights (made on first use after binding): key = the engine's fp32 copy
+    std::map<const float*, uint16_t*> wplanes;
+    int planes = 1;             // pre-split operands + LDS-DMA GEMM for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
 };
 
 extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, MttsCodec** out) {
@@ -758,6 +920,8 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     k->c = *c;
     k->device = device;
     if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
+    if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
+    if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
     *out = k;
@@ -769,6 +933,7 @@ extern "C" int32_t mtts_codec_destroy(MttsCodec* k) {
     hipSetDevice(k->device);
     hipDeviceSynchronize();
     for (auto& kv : k->w) hipFree(kv.second);
+    for (auto& kv : k->wplanes) hipFree(kv.second);
     float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->bufE, k->big, k->scores, k->melbuf, k->melmax};
     for (float* p : bufs) if (p) hipFree(p);
     if (k->d_lens2) hipFree(k->d_lens2);
@@ -787,7 +952,11 @@ extern "C" int32_t mtts_codec_bind(MttsCodec* k, const char* role, const float* 
     if (!k || !role || !dev || n < 1) return cfail(MTTS_EINVAL, "bad argument");
     CHK(hipSetDevice(k->device));
     std::string r(role);
-    if (k->w.count(r)) { hipFree(k->w[r]); k->w.erase(r); }
+    if (k->w.count(r)) {
+        auto pl = k->wplanes.find(k->w[r]);
+        if (pl != k->wplanes.end()) { CHK(hipDeviceSynchronize()); hipFree(pl->second); k->wplanes.erase(pl); }
+        hipFree(k->w[r]); k->w.erase(r);
+    }
     float* p = nullptr;
     CHK(hipMalloc((void**)&p, (size_t)n * 4));
     CHK(hipMemcpyAsync(p, dev, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -796,6 +965,11 @@ extern "C" int32_t mtts_codec_bind(MttsCodec* k, const char* role, const float* 
     return MTTS_OK;
 }
 
+#define TRYC(x)            \
+    do {                   \
+        int _r = (x);      \
+        if (_r) return _r; \
+    } while (0)
 static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
     auto it = k->w.find(name);
     if (it == k->w.end()) return cfail(MTTS_ESTATE, "codec tensor '%s' is not bound", name.c_str());
@@ -810,6 +984,35 @@ static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
         if (_r) return _r;                          \
     } while (0)
 
+// C[M,N] = epi(A * W^T) on pre-split operands (gemm_b3t_kernel).  A: fragment-packed bf16 hi plane at `a_planes`, lo plane
+// pad32(M) rows further; W: the engine's fp32 weight, split + packed on first use.  Output: fp32 `C` (bias / GELU /
+// gamma / residual as gemm_f32) or, with c_planes, fragment-packed planes in the same buffer (the next GEMM's A).
+static bool planes_ok(const MttsCodec* k, int K, long lda) { return k->planes && g_gemm_split && K % 64 == 0 && lda == K; }
+static inline long pad32(long r) { return (r + 31) / 32 * 32; }
+static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long a_rows, const float* W, float* C, int M, int N,
+                       int K, long lda, long ldc, const float* bias, int act, const float* gamma, const float* res, long ldres,
+                       bool c_planes, long c_rows) {
+    (void)a_rows; (void)c_rows; (void)lda;
+    if (N % 4) return cfail(MTTS_EINVAL, "gemm_planes: N must be a multiple of 4");
+    uint16_t* wp = nullptr;
+    const long wn = pad32(N) * (long)K;                      // elements per weight plane
+    auto it = k->wplanes.find(W);
+    if (it == k->wplanes.end()) {
+        CHK(hipMalloc((void**)&wp, (size_t)wn * 4));
+        CHK(hipMemsetAsync(wp, 0, (size_t)wn * 4, st));
+        const long n = (long)N * K;
+        hipLaunchKernelGGL(split_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, wp, wp + wn, N, K);
+        CHK(hipStreamSynchronize(st));           // once per weight: later calls may come in on another stream
+        k->wplanes[W] = wp;
+    } else wp = it->second;
+    // activation planes: hi plane first, lo plane pad32(M) rows further (both in fragment order, K = row length)
+    GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
+                  (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
+                  c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
+    hipLaunchKernelGGL(gemm_b3t_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, 1), dim3(256), 0, st, g);
+    return 0;
+}
+
 static int ensure_workspace(MttsCodec* k, int B, int T) {
     if (B <= k->cap_B && T <= k->cap_T) return 0;
     B = std::max(B, k->cap_B);            // never shrink one dimension while growing the other
@@ -819,7 +1022,7 @@ static int ensure_workspace(MttsCodec* k, int B, int T) {
     for (float* p : bufs) if (p) hipFree(p);
     if (k->d_codes) { hipFree(k->d_codes); hipFree(k->d_lens); hipFree(k->d_lens4); hipFree(k->d_lens2); }
     const int up = c.up_stride;
-    const size_t r100 = (size_t)B * (2 * (size_t)T * up + 3);        // frames at the 100 Hz stage (+ deconv slack)
+    const size_t r100 = (size_t)B * (2 * (size_t)T * up + 3) + 32;   // frames at the 100 Hz stage (+ deconv slack, + the fragment-packed planes' row padding)
     size_t wide = std::max<size_t>({(size_t)c.quant_out_dim, (size_t)3 * c.adapter_dim, (size_t)3 * c.dec_dim,
                                     (size_t)c.voc_dim, (size_t)7 * c.mel_bins, (size_t)c.n_fft + 16});
     size_t n_small = r100 * wide;
@@ -867,7 +1070,8 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, u32x4_t
 }
 
 __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict__ qkv, float* __restrict__ att,
-                                                         const int* __restrict__ lens, int T, int d, float scale) {
+                                                         const int* __restrict__ lens, int T, int d, float scale,
+                                                         uint16_t* __restrict__ att_lo = nullptr) {
     const int b = blockIdx.z, head = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 5, ql = lane & 31;
     const int q = blockIdx.x * 128 + wave * 32 + ql;
@@ -982,11 +1186,17 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
     }
     if (q < T) {
         const float inv = 1.0f / l_run;
-        float* op = att + ((long)b * T + q) * d + head * 64;
+        const long ob = ((long)b * T + q) * d + head * 64;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) op[32 * t + (i & 3) + 8 * (i >> 2) + 4 * g] = o[t][i] * inv;
+            for (int i = 0; i < 16; ++i) {
+                const int col = head * 64 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (att_lo) {                                  // fragment-packed planes for the pre-split o_proj GEMM
+                    const size_t at = xpack_off(b * T + q, col, d);
+                    split1(o[t][i] * inv, ((uint16_t*)att)[at], att_lo[at]);
+                } else att[ob - head * 64 + col] = o[t][i] * inv;
+            }
     }
 }
 
@@ -1001,6 +1211,22 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
     NEED(ln2w, p + "ln2.w", d); NEED(ln2b, p + "ln2.b", d);
     NEED(w1, p + "fc1.w", (size_t)ffn * d); NEED(b1, p + "fc1.b", ffn);
     NEED(w2, p + "fc2.w", (size_t)d * ffn); NEED(b2, p + "fc2.b", d);
+    if (g_gemm_split && hd == 64 && planes_ok(k, d, d) && planes_ok(k, ffn, ffn)) {
+        // decode direction, pre-split operands: every activation that only feeds a GEMM is written as bf16 hi / lo planes
+        // by its producer (same buffers: hi plane first, lo plane `rows` rows further), weights are split once
+        uint16_t* tlo = (uint16_t*)tmp + pad32(rows) * d;
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln1w, ln1b, tmp, rows, d, 1e-5f,
+                           (const int*)nullptr, T, (long)d, tlo);
+        TRYC(gemm_planes(k, st, tmp, rows, wqkv, qkv, rows, 3 * d, d, d, 3 * d, bqkv, 0, nullptr, nullptr, 0, false, 0));
+        hipLaunchKernelGGL(codec_attn_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, (const float*)qkv, att,
+                           d_lens, T, d, 1.0f / sqrtf((float)hd), (uint16_t*)att + pad32(rows) * d);
+        TRYC(gemm_planes(k, st, att, rows, wo, x, rows, d, d, d, d, bo, 0, nullptr, x, d, false, 0));      // x += out_proj(att)
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln2w, ln2b, tmp, rows, d, 1e-5f,
+                           (const int*)nullptr, T, (long)d, tlo);
+        TRYC(gemm_planes(k, st, tmp, rows, w1, k->big, rows, ffn, d, d, ffn, b1, 1, nullptr, nullptr, 0, true, rows));
+        TRYC(gemm_planes(k, st, k->big, rows, w2, x, rows, d, ffn, ffn, d, b2, 0, nullptr, x, d, false, 0));  // x += fc2(gelu(fc1))
+        return 0;
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln1w, ln1b, tmp, rows, d, 1e-5f,
                        (const int*)nullptr, T, (long)d);
     gemm_f32(st, false, tmp, wqkv, qkv, rows, 3 * d, d, d, d, 3 * d, bqkv);
@@ -1158,6 +1384,13 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
         NEED(p1_w, p + "pw1.w", (size_t)vi * vd); NEED(p1_b, p + "pw1.b", vi);
         NEED(p2_w, p + "pw2.w", (size_t)vd * vi); NEED(p2_b, p + "pw2.b", vd);
         NEED(gam, p + "gamma", vd);
+        if (planes_ok(k, vd, vd) && planes_ok(k, vi, vi)) {
+            hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
+                               vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+            TRYC(gemm_planes(k, st, Cc, rows8, p1_w, k->big, rows8, vi, vd, vd, vi, p1_b, 1, nullptr, nullptr, 0, true, rows8));
+            TRYC(gemm_planes(k, st, k->big, rows8, p2_w, A, rows8, vd, vi, vi, vd, p2_b, 0, gam, A, vd, false, 0));   // h += gamma * pw2(..)
+            continue;
+        }
         hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
                            vd, 1e-6f);
         gemm_f32(st, false, Cc, p1_w, k->big, rows8, vi, vd, vd, vd, vi, p1_b, 1);
