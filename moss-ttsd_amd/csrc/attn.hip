@@ -155,19 +155,22 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     }
 }
 
-// grid = (ceil(pages/ATT_PB), nkv, R); block 256.  V page is [token pair][d][2]: one dword holds
+#ifndef PV_WAVES
+#define PV_WAVES 4            // waves per pass-B block (ATT_PB / PV_WAVES pages each)
+#endif
+// grid = (ceil(pages/ATT_PB), nkv, R); block PV_WAVES x 64.  V page is [token pair][d][2]: one dword holds
 // (v[2i][d], v[2i+1][d]) so that P.V is a v_dot2c_f32_bf16 against the packed (already bf16-rounded,
 // hence exact) probability pair: out[d] += p[2i]*v[2i][d] + p[2i+1]*v[2i+1][d].  Lane l covers
 // d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
 // FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
 // writes it to the cache and patches it into the page it has just loaded.
 template <int G, bool FUSED>
-__global__ __launch_bounds__(256) void attn_pv_kernel(
+__global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
     int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f) {
-    __shared__ float red[4][G][MTTS_HD];
-    __shared__ uint16_t pbuf[4][G][MTTS_PAGE];
+    __shared__ float red[PV_WAVES][G][MTTS_HD];
+    __shared__ uint16_t pbuf[PV_WAVES][G][MTTS_PAGE];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[MTTS_HD];
     const int r = blockIdx.z, kvh = blockIdx.y, chunk = blockIdx.x;
     const RowMeta m = meta[r];
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
     const int sub = lane >> 5, dl = lane & 31;
     // V loads of this wave's first page go out before the softmax statistics are reduced
     u32x4_t vv[16];
-    int pg = chunk * ATT_PB + wave * (ATT_PB / 4);
+    int pg = chunk * ATT_PB + wave * (ATT_PB / PV_WAVES);
     if (pg < npages) {
         const int page = page_table[(size_t)m.seq * max_pages + pg];
         const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
         for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
     }
     const int own_pg = m.pos >> 6;
-    const bool own_wave = FUSED && own_pg >= pg && own_pg < pg + ATT_PB / 4;       // one wave per (row, kv head)
+    const bool own_wave = FUSED && own_pg >= pg && own_pg < pg + ATT_PB / PV_WAVES;       // one wave per (row, kv head)
     if (own_wave) {
         float a, b;
         fuse_reduce(f, r, (nq + nkv + kvh) * MTTS_HD, lane, a, b);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[g][i] = 0.f;
 #pragma unroll 1
-    for (int pp = 0; pp < ATT_PB / 4; ++pp, ++pg) {
+    for (int pp = 0; pp < ATT_PB / PV_WAVES; ++pp, ++pg) {
         if (pg >= npages) break;
         if (pp > 0) {
             const int page = page_table[(size_t)m.seq * max_pages + pg];
@@ -283,9 +286,11 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(
             if (sub == 0) red[wave][g][dl * 4 + i] = v;
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < G * MTTS_HD; i += 256) {
+    for (int i = threadIdx.x; i < G * MTTS_HD; i += PV_WAVES * 64) {
         int g = i / MTTS_HD, d = i % MTTS_HD;
-        float v = red[0][g][d] + red[1][g][d] + red[2][g][d] + red[3][g][d];
+        float v = red[0][g][d];
+#pragma unroll
+        for (int w = 1; w < PV_WAVES; ++w) v += red[w][g][d];
         opart[(((size_t)r * nq + kvh * G + g) * nchunks_max + chunk) * MTTS_HD + d] = v;
     }
 }
@@ -551,10 +556,10 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
         if (fuse)
-            hipLaunchKernelGGL((attn_pv_kernel<G, true>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+            hipLaunchKernelGGL((attn_pv_kernel<G, true>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
                                (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
         else
-            hipLaunchKernelGGL((attn_pv_kernel<G, false>), gb, dim3(256), 0, st, (const uint16_t*)scores, (const float*)stats,
+            hipLaunchKernelGGL((attn_pv_kernel<G, false>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
                                (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
     }
     if (phase == 0 || phase == 3)

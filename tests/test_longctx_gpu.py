@@ -36,16 +36,20 @@ def _long_prompts(cfg, seed, lens, audio_frac=0.3):
     return synth.left_pad(seqs, cfg["pad_token_id"])
 
 
-@pytest.mark.parametrize("ctx,fuse", [(2100, "1000000"), (2100, "0"), (4200, "1000000"), (4200, "0"),
-                                      (8300, "1000000"), (8300, "0")])
-def test_long_context_decode_vs_oracle(monkeypatch, ctx, fuse):
+@pytest.mark.parametrize("ctx,fuse,pf_rows", [(2100, "1000000", False), (2100, "0", False), (4200, "1000000", False),
+                                              (4200, "0", True), (8300, "1000000", False), (8300, "0", False)])
+def test_long_context_decode_vs_oracle(monkeypatch, ctx, fuse, pf_rows):
     """B=2 ragged prompts of ~ctx tokens (tiny dims), then 70 greedy decode steps across a page boundary: the
     oracle's run replayed through the engine.  ctx 8300 = 130 KV pages: the softmax statistics loop of attn_pv
     walks the per-page pairs in three strides and attn_combine sums 17 pass-B chunks; prefill runs 5 passes of 2048
     rows through the tile-sharing MFMA attention.  `fuse` selects the decode q/k/v epilogue inside the attention
-    kernels ("1000000") or as its own launch ("0": what a full-size batch at 4 k runs)."""
+    kernels ("1000000") or as its own launch ("0": what a full-size batch at 4 k runs); `pf_rows` sends the 4 200-token
+    ragged prompt through the row-by-row prefill attention instead of the tile-sharing MFMA kernels, so both prefill
+    attention paths are checked at a 4 k prompt."""
     from mtts.engine import Engine
     monkeypatch.setenv("MTTS_FUSE_QKV_MAX", fuse)
+    if pf_rows:
+        monkeypatch.setenv("MTTS_PREFILL_MFMA_PAGES", "100000")
     cfg = synth.tiny(max_position_embeddings=16384)
     w = synth.synth_weights(cfg, 141, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
     ids, mask = _long_prompts(cfg, 142, [ctx, ctx - 37 - ctx // 9])
