@@ -138,10 +138,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
         if (u < n) a[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
     const int kt_base = (PRO == PRO_NORM) ? 0 : kb0;
     if (PRO == PRO_NORM) {
+        const int H = KT * 16;
         // Two passes over the row with x' parked (as bf16, exactly what the residual stream stores) in the LDS slot
         // that will hold xn: nothing but the running sum of squares lives in registers across the block-wide sum, so
         // the kernel keeps two 512-thread blocks per CU (a register-resident row cost 200 VGPRs = one block).
-        const int H = KT * 16;
         constexpr int G = WAVES / 4;                                   // rows handled at a time (256 threads each)
         const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
         const size_t kstride = (size_t)MTTS_PFCAP * pr.slab_npad;
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
             const int r = r0 + g;
             const bool act = r < pr.rows;
             float ss = 0.f;
+            // the norm weights of this thread's first chunk travel with the row's loads (one round trip, not two)
+            const u32x4_t nw0 = (t * 8 < H) ? *(const u32x4_t*)(pr.norm_w + t * 8) : u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll 1
             for (int i0 = t * 8; i0 < H; i0 += 2048) {
                 if (!act) break;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
 #pragma unroll 1
             for (int i0 = t * 8; i0 < H; i0 += 2048) {
                 if (!act) break;
-                const u32x4_t w = *(const u32x4_t*)(pr.norm_w + i0);
+                const u32x4_t w = (i0 == t * 8) ? nw0 : *(const u32x4_t*)(pr.norm_w + i0);
                 const u32x4_t xv = xs[(size_t)(i0 >> 3) * SMALL_RP + r];
                 u32x4_t y;
                 y.x = pack2(bflo(w.x) * rbf(bflo(xv.x) * inv), bfhi(w.x) * rbf(bfhi(xv.x) * inv));
@@ -215,12 +217,20 @@ __global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
         for (int idx = threadIdx.x; idx < pr.rows * len; idx += WAVES * 64) {
             const int r = idx / len, k = k_lo + idx % len;
             const int h = k >> 7, d = k & 127;
+            // the first 8 chunk partials are fetched without waiting for the row's chunk count (the slots exist for
+            // every row; what lies beyond a row's last chunk is simply not added): one round trip instead of two
+            const float* p = pr.opart + ((size_t)r * pr.nq + h) * pr.nchunks_max * MTTS_HD + d;
+            float t0[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t0[j] = p[(size_t)min(j, pr.nchunks_max - 1) * MTTS_HD];
             const RowMeta m = pr.meta[r];
             const int npages = m.seq >= 0 ? (m.pos + 1 + MTTS_PAGE - 1) / MTTS_PAGE : 0;
             const int nch = (npages + pr.pages_per_chunk - 1) / pr.pages_per_chunk;
-            const float* p = pr.opart + ((size_t)r * pr.nq + h) * pr.nchunks_max * MTTS_HD + d;
             float sacc = 0.f;
-            for (int c0 = 0; c0 < nch; c0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nch) sacc += t0[j];
+            for (int c0 = 8; c0 < nch; c0 += 8) {
                 float tt[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tt[j] = p[(size_t)min(c0 + j, nch - 1) * MTTS_HD];
