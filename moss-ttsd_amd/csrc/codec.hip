@@ -365,7 +365,8 @@ __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
 // per 16-deep step 8 fragment loads and 12 MFMAs (w_hi*x_lo, w_lo*x_hi, w_hi*x_hi: the products of gemm_b3_kernel).
 // Output: fp32 C (bias / GELU / gamma / residual, float4 per lane) or fragment-packed hi / lo planes for the next GEMM.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_b3t_kernel(GemmF32Args g) {
+template <int U>      // k-steps per register set: 2 = 232 VGPRs, two waves per SIMD; 1 = three waves per SIMD (picked per shape against tile quantisation)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(U == 2 ? 2 : 3, U == 2 ? 2 : 3))) void gemm_b3t_kernel(GemmF32Args g) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntiles = (g.N + 31) / 32, rtiles = (g.M + 31) / 32, KT = g.K / 16;
     int tm_ = blockIdx.y, tn_ = blockIdx.x;
@@ -388,7 +389,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Two register sets of U k-steps each, ping-pong: the loads of one set are issued before the MFMAs of the other and
     // the scheduler is kept from interleaving them back into short-distance load/use pairs (sched_barrier): while a set
     // of 8 U fragments feeds the matrix cores the other 8 U KiB per wave are in flight.
-    constexpr int U = 2;
     struct FragSet { u32x4_t ah[2][U], al[2][U], bh[2][U], bl[2][U]; };
     auto load = [&](FragSet& f, int i0) {
 #pragma unroll
@@ -906,7 +906,8 @@ struct MttsCodec {
     int split_decode = 1;       // decode-direction GEMMs as bf16x3 (MTTS_CODEC_GEMM=f32: exact f32 MFMA)
     // bf16 hi/lo planes of the constant weights (made on first use after binding): key = the engine's fp32 copy
     std::map<const float*, uint16_t*> wplanes;
-    int planes = 1;             // pre-split operands + LDS-DMA GEMM for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
+    int planes = 1;             // pre-split fragment-packed operands for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
+    int occ3 = 1;               // gemm_b3t_kernel: three waves per SIMD where that fills the last round better (MTTS_CODEC_OCC3=0: off)
 };
 
 extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, MttsCodec** out) {
@@ -921,6 +922,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     k->device = device;
     if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
     if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
+    if (const char* m = getenv("MTTS_CODEC_OCC3")) k->occ3 = atoi(m);       // 0 never, 1 by quantisation estimate, 2 always
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
@@ -1009,7 +1011,14 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
     GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
                   (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
                   c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
-    hipLaunchKernelGGL(gemm_b3t_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, 1), dim3(256), 0, st, g);
+    // Tile quantisation: a wave owns a 64 x 64 output tile and all of K, so a launch runs in rounds of (resident waves)
+    // tiles.  With two waves per SIMD 2048 are resident, with three 3072 (shallower prefetch, the same throughput per CU):
+    // take the occupancy whose last round is fuller (pw2: 3000 tiles = 73 % of two rounds of 2048, 98 % of one of 3072).
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    auto eff = [&](long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
+    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, 1);
+    if (k->occ3 == 2 || (k->occ3 && eff(3072) > 1.08 * eff(2048))) hipLaunchKernelGGL(gemm_b3t_kernel<1>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_b3t_kernel<2>, grid, dim3(256), 0, st, g);
     return 0;
 }
 
