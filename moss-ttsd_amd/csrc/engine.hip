@@ -1153,7 +1153,6 @@ int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfi
 // finishes leaves the batch at once (no finished-row padding) and its slot can be refilled.
 int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSamplerCfg* sampler, void* stream) {
     if (!e || !sampler) return fail(MTTS_EINVAL, "null argument");
-    if (e->f32) return fail(MTTS_EINVAL, "continuous batching is built for the bf16 engine only");
     TRY(mtts_weights_ready(e));
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = S(stream);
@@ -1169,7 +1168,7 @@ int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSam
     for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = 0; }
     std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
     HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
-    LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, 0};
+    LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, e->f32 ? 1 : 0};
     e->forced_draw = 0;
     HIPCHK(hipMemcpyAsync(e->d_ls, &ls, sizeof(ls), hipMemcpyHostToDevice, st));
     *e->h_ls = ls;
@@ -1235,17 +1234,26 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     HIPCHK(hipMemcpy(e->d_bitmaps + (size_t)slot * 8 * e->bm_words, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_tf + (size_t)slot * 7 * 8, tf.data(), tf.size() * 4, hipMemcpyHostToDevice));
     const int pages_bound = (n + MTTS_PAGE - 1) / MTTS_PAGE;
-    for (size_t off = 0; off < Mpad; off += MTTS_PFCAP)
-        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, (int)std::min<size_t>(MTTS_PFCAP, Mpad - off),
+    const size_t pfcap = e->f32 ? MTTS_PF32CAP : MTTS_PFCAP;
+    for (size_t off = 0; off < Mpad; off += pfcap)
+        TRY(forward_rows(e, e->d_pf_tokens + off * 8, e->d_pf_meta + off, (int)std::min<size_t>(pfcap, Mpad - off),
                          pages_bound, 0, st, 0));
     // logits of the dialogue's last prompt token only: heads on a one-row activation tile, copied into its slot
     // (the other slots' logits belong to dialogues that are mid-flight)
+    if (e->f32) {            // fp32 engine: the GEMV writes the slot's logits rows directly
+        const float* xin = e->hlast_f + (size_t)slot * e->H;
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0 + (size_t)slot * e->V0, 1, e->V0, e->H, e->V0, st);
+        for (int c = 1; c < 8; ++c)
+            launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)slot * 7 * e->Vs_pad + (size_t)(c - 1) * e->Vs_pad, 1, e->Vs,
+                              e->H, 7 * e->Vs_pad, st);
+    } else {
     HIPCHK(hipMemsetAsync(e->xh, 0, (size_t)MTTS_MAXR * e->H * 2, st));
     launch_pack_rows((const uint16_t*)e->hlast + (size_t)slot * e->H, e->xh, 1, e->H, 1, st);
     launch_gemm(EPI_BF16, 1, e->p_h0, e->head0, e->xh, e->H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->join_logits0, st);
     launch_gemm(EPI_BF16, 1, e->p_h17, e->heads17, e->xh, e->H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->join_logits17, st);
     HIPCHK(hipMemcpyAsync((uint16_t*)e->logits0 + (size_t)slot * e->V0, e->join_logits0, (size_t)e->V0 * 2, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync((uint16_t*)e->logits17 + (size_t)slot * 7 * e->Vs_pad, e->join_logits17, (size_t)7 * e->Vs_pad * 2, hipMemcpyDeviceToDevice, st));
+    }
     SeqState ns{-1, 1, n, 0, base, max_length, 0, 1, seed};
     HIPCHK(hipMemcpyAsync(e->d_seqs + slot, &ns, sizeof(ns), hipMemcpyHostToDevice, st));
     int32_t zero = 0;

@@ -714,3 +714,32 @@ def test_paged_attn_decode_kernel_vs_oracle(nq, nkv):
                                             R, Lmax, nq, nkv, out2.data_ptr(), None))
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+def test_fp32_continuous_batching_equals_standalone():
+    """The fp32 engine under the continuous batcher: 6 dialogues through 2 slots, every dialogue's tokens equal its
+    batch-1 run (greedy and sampled with per-dialogue Philox keys)."""
+    from mtts.engine import Engine
+    from mtts.scheduler import ContinuousBatcher
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 191, bf16=False, emb_row_sigma=0.6, speech_boost=5.0, eos_boost=5.0)
+    eng = Engine(cfg, max_batch=2, max_seq_len=256, dtype="fp32")
+    eng.bind_state_dict(w)
+    solo = Engine(cfg, max_batch=1, max_seq_len=256, dtype="fp32")
+    solo.bind_state_dict(w)
+    rng = np.random.default_rng(7)
+    prompts, mnts = [], []
+    for i in range(6):
+        n = int(rng.integers(6, 40))
+        raw = np.full((n, 8), 1024, dtype=np.int64)
+        raw[:, 0] = rng.integers(0, 151643, n)
+        prompts.append(synth.shifting_inputs(raw, cfg["pad_token_id"]))
+        mnts.append(int(rng.integers(5, 30)))
+    for layers, ds in ((None, None), ([dict(top_k=20, top_p=0.9, temperature=1.1)] * 8, [True] * 8)):
+        cb = ContinuousBatcher(eng, slots=2, gen_cap=64, layers=layers, do_samples=ds, steps_per_poll=4)
+        got = cb.run(prompts, mnts, base_seed=40)
+        for i, p in enumerate(prompts):
+            alone = solo.generate(p[None], np.ones((1, p.shape[0])), p.shape[0] + mnts[i], layers=layers, do_samples=ds, seed=40 + i)[0]
+            assert got[i].shape == alone.shape and np.array_equal(got[i], alone), i
+    eng.close()
+    solo.close()
