@@ -128,7 +128,7 @@ struct MttsEngine {
     int emb_bound = 0, norm_bound = 0;
     const uint16_t** d_tables = nullptr;
     // plans
-    GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17;
+    GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17, p_h0s;     // p_h0s: head 0 in the small-batch path (4 waves measured faster there)
     // workspaces
     float* partial = nullptr;
     float* partial2 = nullptr;          // small-batch path: o_proj / down_proj slabs (the qkv slabs stay in `partial`)
@@ -306,7 +306,7 @@ static int create_f32(MttsEngine* e) {
     TRY(dalloc(&e->qkvf, P * e->qkv_rows)); TRY(dalloc(&e->qbuf_f, P * e->nq * D)); TRY(dalloc(&e->attnf, P * e->nq * D));
     TRY(dalloc(&e->guf, P * 2 * I)); TRY(dalloc(&e->actf, P * I));
     TRY(dalloc(&e->hlast_f, (size_t)MTTS_RCAP * H));
-    TRY(dalloc((float**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
+    TRY(dalloc((float**)&e->logits0, (size_t)MTTS_RCAP * e->V0_pad));
     TRY(dalloc((float**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
     return 0;
 }
@@ -337,7 +337,7 @@ static int forward_rows_f32(MttsEngine* e, const int32_t* d_tokens, const RowMet
     if (heads) {
         // decode rows are the dialogues themselves (row b = slot b); after a prefill the last tokens' states are in hlast
         const float* xin = heads == 1 ? e->xnf : e->hlast_f;
-        launch_f32_linear(e->embf[0], xin, (float*)e->logits0, e->B, e->V0, H, e->V0, st);
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0, e->B, e->V0, H, e->V0_pad, st);
         for (int c = 1; c < 8; ++c)
             launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)(c - 1) * e->Vs_pad, e->B, e->Vs, H, 7 * e->Vs_pad, st);
     }
@@ -403,6 +403,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->p_d = mtts_plan_gemm(round_up(H, 32), I, 0);
     e->p_h0 = mtts_plan_gemm(e->V0_pad, H, 1);
     e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
+    e->p_h0s = (H / 16) / 4 >= 4 ? mtts_plan_gemm_forced(e->V0_pad, H, 1, 4) : e->p_h0;
     // activations hold a whole prefill pass (MTTS_PFCAP rows); split-K slabs: up to 8 of [MTTS_PFCAP][Npad] fp32
     size_t pmax = (size_t)8 * std::max(e->qkv_rows, round_up(H, 32));
     if (!e->f32) {
@@ -417,9 +418,9 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->attn_p, (size_t)MTTS_PFCAP * e->nq * MTTS_HD));
     TRY(dalloc((uint16_t**)&e->act_p, (size_t)MTTS_PFCAP * I));
     TRY(dalloc((uint16_t**)&e->qbuf, (size_t)MTTS_PFCAP * e->nq * MTTS_HD));
-    TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_RCAP * e->V0));
+    TRY(dalloc((uint16_t**)&e->logits0, (size_t)MTTS_RCAP * e->V0_pad));        // channel-0 rows padded to 32 tokens
     TRY(dalloc((uint16_t**)&e->logits17, (size_t)MTTS_RCAP * 7 * e->Vs_pad));
-    TRY(dalloc((uint16_t**)&e->join_logits0, (size_t)MTTS_MAXR * e->V0));
+    TRY(dalloc((uint16_t**)&e->join_logits0, (size_t)MTTS_MAXR * e->V0_pad));
     TRY(dalloc((uint16_t**)&e->join_logits17, (size_t)MTTS_MAXR * 7 * e->Vs_pad));
     }
     // KV pool
@@ -719,7 +720,7 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
     }
     SmallPro ph = base;                                // final norm (+ the last down_proj slabs) in front of the 8 heads
     ph.x_in = xa; ph.x_out = nullptr; ph.slabs = e->partial2; ph.ksplit = e->p_d.ksplit; ph.norm_w = (const uint16_t*)e->final_norm;
-    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h0, e->head0, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, ph, st);
+    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h0s, e->head0, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, ph, st);
     launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h17, e->heads17, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, ph, st);
     HIPCHK(hipGetLastError());
     return MTTS_OK;
@@ -1060,7 +1061,7 @@ int32_t mtts_read_logits_f32(MttsEngine* e, float* l0, float* l17, void* stream)
     if (!e->f32) return fail(MTTS_ESTATE, "bf16 engine: use mtts_read_logits");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(S(stream)));
-    if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 4, hipMemcpyDeviceToHost));
+    if (l0) HIPCHK(hipMemcpy2D(l0, (size_t)e->V0 * 4, e->logits0, (size_t)e->V0_pad * 4, (size_t)e->V0 * 4, e->B, hipMemcpyDeviceToHost));
     if (l17) {
         std::vector<float> tmp((size_t)MTTS_RCAP * 7 * e->Vs_pad);
         HIPCHK(hipMemcpy(tmp.data(), e->logits17, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -1076,7 +1077,7 @@ int32_t mtts_read_logits(MttsEngine* e, uint16_t* l0, uint16_t* l17, void* strea
     if (e->f32) return fail(MTTS_ESTATE, "fp32 engine: use mtts_read_logits_f32");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(S(stream)));
-    if (l0) HIPCHK(hipMemcpy(l0, e->logits0, (size_t)e->B * e->V0 * 2, hipMemcpyDeviceToHost));
+    if (l0) HIPCHK(hipMemcpy2D(l0, (size_t)e->V0 * 2, e->logits0, (size_t)e->V0_pad * 2, (size_t)e->V0 * 2, e->B, hipMemcpyDeviceToHost));
     if (l17) {
         std::vector<uint16_t> tmp((size_t)MTTS_RCAP * 7 * e->Vs_pad);
         HIPCHK(hipMemcpy(tmp.data(), e->logits17, tmp.size() * 2, hipMemcpyDeviceToHost));
@@ -1242,7 +1243,7 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     // (the other slots' logits belong to dialogues that are mid-flight)
     if (e->f32) {            // fp32 engine: the GEMV writes the slot's logits rows directly
         const float* xin = e->hlast_f + (size_t)slot * e->H;
-        launch_f32_linear(e->embf[0], xin, (float*)e->logits0 + (size_t)slot * e->V0, 1, e->V0, e->H, e->V0, st);
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0 + (size_t)slot * e->V0_pad, 1, e->V0, e->H, e->V0_pad, st);
         for (int c = 1; c < 8; ++c)
             launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)slot * 7 * e->Vs_pad + (size_t)(c - 1) * e->Vs_pad, 1, e->Vs,
                               e->H, 7 * e->Vs_pad, st);
@@ -1251,7 +1252,7 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     launch_pack_rows((const uint16_t*)e->hlast + (size_t)slot * e->H, e->xh, 1, e->H, 1, st);
     launch_gemm(EPI_BF16, 1, e->p_h0, e->head0, e->xh, e->H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->join_logits0, st);
     launch_gemm(EPI_BF16, 1, e->p_h17, e->heads17, e->xh, e->H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->join_logits17, st);
-    HIPCHK(hipMemcpyAsync((uint16_t*)e->logits0 + (size_t)slot * e->V0, e->join_logits0, (size_t)e->V0 * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync((uint16_t*)e->logits0 + (size_t)slot * e->V0_pad, e->join_logits0, (size_t)e->V0 * 2, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync((uint16_t*)e->logits17 + (size_t)slot * 7 * e->Vs_pad, e->join_logits17, (size_t)7 * e->Vs_pad * 2, hipMemcpyDeviceToDevice, st));
     }
     SeqState ns{-1, 1, n, 0, base, max_length, 0, 1, seed};

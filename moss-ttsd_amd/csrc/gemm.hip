@@ -81,11 +81,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + row) * Npad + n0) = o;
             } else if (EPI == EPI_BF16) {
-                // row-major [rows][n_valid] bf16 (logits): rows are not 8-byte aligned when n_valid is odd
-                uint16_t* o = out + (size_t)row * n_valid + n0;
+                // row-major [rows][Npad] bf16 (logits; columns >= n_valid are padding): rows are 64-byte aligned, a lane's four
+                // consecutive columns go out as one 8-byte store
+                uint16_t* o = out + (size_t)row * Npad + n0;
+                if (n0 + 3 < n_valid) *(u32x2_t*)o = u32x2_t{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                }
             } else {
                 // rows interleaved gate,up,gate,up: SwiGLU (modeling_qwen3.py:81-83) with the
                 // reference's bf16 rounding points: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
@@ -305,10 +309,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void gemv_small_kernel(
         if (EPI == EPI_PARTIAL) {
             *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + orow) * Npad + n0) = make_float4(v[0], v[1], v[2], v[3]);
         } else if (EPI == EPI_BF16) {
-            uint16_t* o = out + (size_t)orow * n_valid + n0;
+            uint16_t* o = out + (size_t)orow * Npad + n0;
+            if (n0 + 3 < n_valid) *(u32x2_t*)o = u32x2_t{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+            }
         } else {                                               // EPI_SILU_RM: gate,up interleaved rows -> [rows][Npad/2]
             uint32_t w2;
             {
@@ -394,10 +401,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                 if (EPI == EPI_PARTIAL) {
                     *(float4*)(partial + ((size_t)ks * MTTS_PFCAP + row) * Npad + n0) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if (EPI == EPI_BF16) {
-                    uint16_t* o = out + (size_t)row * n_valid + n0;
+                    uint16_t* o = out + (size_t)row * Npad + n0;
+                    if (n0 + 3 < n_valid) *(u32x2_t*)o = u32x2_t{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                        for (int j = 0; j < 4; ++j)
+                            if (n0 + j < n_valid) o[j] = f2bf(v[j]);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -477,7 +487,7 @@ static GemmPlan plan_gemm(int Npad, int K, int want_ksplit) {
     p.kt_per_split = (KT + ks - 1) / ks;
     int w = 8;
     while (w > 1 && p.kt_per_split / w < 4) w >>= 1;
-    if (ntiles * ks >= 2048 && w > 4) w = 4;
+    // (very wide GEMMs -- head 0 -- used to run faster with 4 waves; with 8-byte logit stores 8 waves win: 115 vs 126 us)
     p.waves = w;
     p.kt_per_wave = (p.kt_per_split + w - 1) / w;
     return p;

@@ -135,7 +135,8 @@ __device__ __forceinline__ bool sample_ctx(SampleCtx& x, int b, int c_in, const 
         x.seed = sq.seed; x.row_id = (uint32_t)sq.row_id;
         x.V = (x.c == 0) ? V0 : Vs;
         {
-            const size_t off = (x.c == 0) ? (size_t)b * V0 : ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
+            // channel-0 rows are padded to a multiple of 32 tokens (aligned rows: the head GEMM stores 8 bytes per lane)
+            const size_t off = (x.c == 0) ? (size_t)b * ((V0 + 31) & ~31) : ((size_t)b * 7 + (x.c - 1)) * Vs_pad;
             const char* base = (const char*)((x.c == 0) ? logits0 : logits17);
             x.lg = LogitsPtr{base + off * (ls->logits_f32 ? 4 : 2), ls->logits_f32};
         }
