@@ -128,7 +128,7 @@ struct MttsEngine {
     int emb_bound = 0, norm_bound = 0;
     const uint16_t** d_tables = nullptr;
     // plans
-    GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17, p_h0s;     // p_h0s: head 0 in the small-batch path (4 waves measured faster there)
+    GemmPlan p_qkv, p_o, p_gu, p_d, p_h0, p_h17;
     // workspaces
     float* partial = nullptr;
     float* partial2 = nullptr;          // small-batch path: o_proj / down_proj slabs (the qkv slabs stay in `partial`)
@@ -403,7 +403,6 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->p_d = mtts_plan_gemm(round_up(H, 32), I, 0);
     e->p_h0 = mtts_plan_gemm(e->V0_pad, H, 1);
     e->p_h17 = mtts_plan_gemm(7 * e->Vs_pad, H, 1);
-    e->p_h0s = (H / 16) / 4 >= 4 ? mtts_plan_gemm_forced(e->V0_pad, H, 1, 4) : e->p_h0;
     // activations hold a whole prefill pass (MTTS_PFCAP rows); split-K slabs: up to 8 of [MTTS_PFCAP][Npad] fp32
     size_t pmax = (size_t)8 * std::max(e->qkv_rows, round_up(H, 32));
     if (!e->f32) {
@@ -720,7 +719,9 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
     }
     SmallPro ph = base;                                // final norm (+ the last down_proj slabs) in front of the 8 heads
     ph.x_in = xa; ph.x_out = nullptr; ph.slabs = e->partial2; ph.ksplit = e->p_d.ksplit; ph.norm_w = (const uint16_t*)e->final_norm;
-    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h0s, e->head0, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, ph, st);
+    // (same plan as the general path: a different K partition over the waves would change the fp32 sums, and with them
+    //  the bit-identity of a dialogue's logits across batch sizes; 4 waves would be 1 % faster at B=1)
+    launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h0, e->head0, H, e->V0_pad, e->V0, nullptr, (uint16_t*)e->logits0, ph, st);
     launch_gemv_small(EPI_BF16, PRO_NORM, e->p_h17, e->heads17, H, 7 * e->Vs_pad, 7 * e->Vs_pad, nullptr, (uint16_t*)e->logits17, ph, st);
     HIPCHK(hipGetLastError());
     return MTTS_OK;
