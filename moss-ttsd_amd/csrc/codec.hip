@@ -365,53 +365,66 @@ __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
 // per 16-deep step 8 fragment loads and 12 MFMAs (w_hi*x_lo, w_lo*x_hi, w_hi*x_hi: the products of gemm_b3_kernel).
 // Output: fp32 C (bias / GELU / gamma / residual, float4 per lane) or fragment-packed hi / lo planes for the next GEMM.
 // ------------------------------------------------------------------------------------
-template <int U>      // k-steps per register set: 2 = 232 VGPRs, two waves per SIMD; 1 = three waves per SIMD (picked per shape against tile quantisation)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(U == 2 ? 2 : 3, U == 2 ? 2 : 3))) void gemm_b3t_kernel(GemmF32Args g) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// NA x NB = 32-wide tiles per wave along n / along rows (a wave owns 32 NA columns x 32 NB rows, a block 2 x 2 waves);
+// U = k-steps per register set; OCC = waves per SIMD the register budget is cut for.
+//   <2,2,2,2>: 232 VGPRs, two waves per SIMD, 683 operand bytes per MFMA through the vector L1;  <2,2,1,3>: three waves;
+//   <4,2,1,2>: 512 bytes per MFMA;  <4,4,1,1>: 341 bytes per MFMA, one wave per SIMD (accumulators = 256 registers).
+// The vector L1 returns 64 B/clk per CU and the four matrix pipes of a CU retire one MFMA per 8 clk between them, so
+// 683 bytes per MFMA is L1-bound before it is MFMA-bound (measured: operand stream alone = 6.1 GB / 218 us = 64.7 B/clk/CU).
+template <int NA, int NB, int U, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void gemm_b3t_kernel(GemmF32Args g) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ntiles = (g.N + 31) / 32, rtiles = (g.M + 31) / 32, KT = g.K / 16;
     int tm_ = blockIdx.y, tn_ = blockIdx.x;
-    if (g_xcd_map) xcd_tile((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, tm_, tn_);
-    const int nt0 = tn_ * 4 + (wave & 1) * 2, rt0 = tm_ * 4 + (wave >> 1) * 2;
+    if (g_xcd_map) xcd_tile((g.M + 64 * NB - 1) / (64 * NB), (g.N + 64 * NA - 1) / (64 * NA), tm_, tn_);
+    const int nt0 = tn_ * 2 * NA + (wave & 1) * NA, rt0 = tm_ * 2 * NB + (wave >> 1) * NB;
     if (nt0 >= ntiles || rt0 >= rtiles) return;
-    const bool n1 = nt0 + 1 < ntiles, r1 = rt0 + 1 < rtiles;
-    f32x16_t acc[2][2];
+    f32x16_t acc[NA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     const size_t xtile = (size_t)KT * 64;                    // one 32-row / 32-column tile, in 16-byte units
-    const u32x4_t* wh[2] = {(const u32x4_t*)g.Whi + (size_t)nt0 * xtile + lane, (const u32x4_t*)g.Whi + (size_t)(n1 ? nt0 + 1 : nt0) * xtile + lane};
-    const u32x4_t* wl[2] = {(const u32x4_t*)g.Wlo + (size_t)nt0 * xtile + lane, (const u32x4_t*)g.Wlo + (size_t)(n1 ? nt0 + 1 : nt0) * xtile + lane};
-    const u32x4_t* xh[2] = {(const u32x4_t*)g.Ahi + (size_t)rt0 * xtile + lane, (const u32x4_t*)g.Ahi + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + lane};
-    const u32x4_t* xl[2] = {(const u32x4_t*)g.Alo + (size_t)rt0 * xtile + lane, (const u32x4_t*)g.Alo + (size_t)(r1 ? rt0 + 1 : rt0) * xtile + lane};
+    // tiles past the edge re-read the last valid one (their accumulators are never stored)
+    const u32x4_t *wh[NA], *wl[NA], *xh[NB], *xl[NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const size_t t = (size_t)min(nt0 + a, ntiles - 1) * xtile;
+        wh[a] = (const u32x4_t*)g.Whi + t + lane; wl[a] = (const u32x4_t*)g.Wlo + t + lane;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const size_t t = (size_t)min(rt0 + b, rtiles - 1) * xtile;
+        xh[b] = (const u32x4_t*)g.Ahi + t + lane; xl[b] = (const u32x4_t*)g.Alo + t + lane;
+    }
     // Two register sets of U k-steps each, ping-pong: the loads of one set are issued before the MFMAs of the other and
     // the scheduler is kept from interleaving them back into short-distance load/use pairs (sched_barrier): while a set
-    // of 8 U fragments feeds the matrix cores the other 8 U KiB per wave are in flight.
-    struct FragSet { u32x4_t ah[2][U], al[2][U], bh[2][U], bl[2][U]; };
+    // feeds the matrix cores the other set's (NA + NB) U KiB x 2 planes per wave are in flight.
+    struct FragSet { u32x4_t ah[NA][U], al[NA][U], bh[NB][U], bl[NB][U]; };
     auto load = [&](FragSet& f, int i0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f.ah[t][u] = wh[t][(size_t)(i0 + u) * 64]; f.al[t][u] = wl[t][(size_t)(i0 + u) * 64];
-                f.bh[t][u] = xh[t][(size_t)(i0 + u) * 64]; f.bl[t][u] = xl[t][(size_t)(i0 + u) * 64];
-            }
+            for (int t = 0; t < NA; ++t) { f.ah[t][u] = wh[t][(size_t)(i0 + u) * 64]; f.al[t][u] = wl[t][(size_t)(i0 + u) * 64]; }
+#pragma unroll
+            for (int t = 0; t < NB; ++t) { f.bh[t][u] = xh[t][(size_t)(i0 + u) * 64]; f.bl[t][u] = xl[t][(size_t)(i0 + u) * 64]; }
+        }
     };
     auto compute = [&](FragSet& f) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.ah[a][u], *(bf16x8_t*)&f.bl[b][u], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.al[a][u], *(bf16x8_t*)&f.bh[b][u], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.ah[a][u], *(bf16x8_t*)&f.bh[b][u], acc[a][b], 0, 0, 0);
                 }
     };
-    FragSet fa, fb;                                  // KT is a multiple of 2 U on this path (gemm_planes checks)
+    FragSet fa, fb;                                  // KT is a multiple of 4 on this path (planes_ok)
     load(fa, 0);
     for (int i = 0; i < KT; i += 2 * U) {
         load(fb, i + U);
@@ -426,11 +439,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(U == 2 ? 2 
     }
     // D[n][row]: lane holds row = lane & 31 and n = 8q + 4(lane>>5) + j (register 4q + j)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        if (a && !n1) break;
+    for (int a = 0; a < NA; ++a) {
+        if (nt0 + a >= ntiles) break;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (b && !r1) break;
+        for (int b = 0; b < NB; ++b) {
+            if (rt0 + b >= rtiles) break;
             const int m = (rt0 + b) * 32 + (lane & 31);
             if (m >= g.M) continue;
 #pragma unroll
@@ -907,7 +920,7 @@ struct MttsCodec {
     // bf16 hi/lo planes of the constant weights (made on first use after binding): key = the engine's fp32 copy
     std::map<const float*, uint16_t*> wplanes;
     int planes = 1;             // pre-split fragment-packed operands for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
-    int occ3 = 1;               // gemm_b3t_kernel: three waves per SIMD where that fills the last round better (MTTS_CODEC_OCC3=0: off)
+    int tile = 0;               // gemm_b3t_kernel: MTTS_CODEC_TILE = NA NB U OCC as digits forces one variant (0: per shape)
 };
 
 extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, MttsCodec** out) {
@@ -922,7 +935,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     k->device = device;
     if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
     if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
-    if (const char* m = getenv("MTTS_CODEC_OCC3")) k->occ3 = atoi(m);       // 0 never, 1 by quantisation estimate, 2 always
+    if (const char* m = getenv("MTTS_CODEC_TILE")) k->tile = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
@@ -1011,14 +1024,36 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
     GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
                   (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
                   c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
-    // Tile quantisation: a wave owns a 64 x 64 output tile and all of K, so a launch runs in rounds of (resident waves)
-    // tiles.  With two waves per SIMD 2048 are resident, with three 3072 (shallower prefetch, the same throughput per CU):
-    // take the occupancy whose last round is fuller (pw2: 3000 tiles = 73 % of two rounds of 2048, 98 % of one of 3072).
-    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    auto eff = [&](long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
-    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, 1);
-    if (k->occ3 == 2 || (k->occ3 && eff(3072) > 1.08 * eff(2048))) hipLaunchKernelGGL(gemm_b3t_kernel<1>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_b3t_kernel<2>, grid, dim3(256), 0, st, g);
+    // Which tile shape: every variant computes the same bits (a tile only decides which wave owns an output element), so
+    // the choice is free to follow the shape.  A CU holds one 4-wave block per wave-per-SIMD of the variant and runs its
+    // share of the grid in sequence: time = ceil(blocks / 256) x (a KT + b + e [GELU epilogue]) with per-variant constants
+    // fitted to a rocprofv3 sweep of all variants over the decoder's ten GEMM shapes (profiles/r02_codec_tile_sweep.json;
+    // the model picks the measured-best variant on each of them).  Big tiles at one wave per SIMD need 341-455 operand
+    // bytes per MFMA from the vector L1 instead of 683 and win wherever K is long (pw2 470 -> 269 us, fc2 314 -> 150 us);
+    // 64 x 96 at two waves per SIMD wins the 512 -> 4096 expansion, whose time is its GELU / split / store epilogue.
+    struct Variant { int code, na, nb; double a, b, e; };
+    static const Variant variants[] = {{2222, 2, 2, 0.594, -3.5, 0.0}, {2312, 2, 3, 0.768, -2.1, -0.4}, {4221, 4, 2, 0.634, 9.6, 4.8},
+                                       {3311, 3, 3, 0.693, 12.5, 2.4}, {3411, 3, 4, 0.862, 13.0, 8.1}, {4311, 4, 3, 0.875, 12.8, 9.9},
+                                       {4411, 4, 4, 1.005, 25.9, 10.5}};
+    auto grid = [&](int na, int nb) { return dim3((N + 64 * na - 1) / (64 * na), (M + 64 * nb - 1) / (64 * nb), 1); };
+    int code = k->tile;                                  // NA NB U OCC as decimal digits (MTTS_CODEC_TILE forces one)
+    if (!code) {
+        double best = 1e30;
+        for (const Variant& v : variants) {
+            const dim3 gr = grid(v.na, v.nb);
+            const double t = (double)(((long)gr.x * gr.y + 255) / 256) * (v.a * (K / 16) + v.b + (act == 1 ? v.e : 0.0));
+            if (t < best) { best = t; code = v.code; }
+        }
+    }
+    switch (code) {
+#define MTTS_B3T(NA, NB, U, OCC) \
+    case NA * 1000 + NB * 100 + U * 10 + OCC: hipLaunchKernelGGL((gemm_b3t_kernel<NA, NB, U, OCC>), grid(NA, NB), dim3(256), 0, st, g); break;
+        MTTS_B3T(2, 2, 2, 2) MTTS_B3T(2, 2, 1, 3) MTTS_B3T(4, 4, 1, 1) MTTS_B3T(4, 3, 1, 1) MTTS_B3T(3, 4, 1, 1) MTTS_B3T(3, 3, 1, 1)
+        MTTS_B3T(4, 2, 2, 1) MTTS_B3T(2, 4, 2, 1) MTTS_B3T(3, 3, 2, 1) MTTS_B3T(3, 2, 1, 2) MTTS_B3T(2, 3, 1, 2) MTTS_B3T(4, 2, 1, 2)
+        MTTS_B3T(2, 4, 1, 2)
+#undef MTTS_B3T
+    default: return cfail(MTTS_EINVAL, "gemm_planes: no kernel for tile code %d", code);
+    }
     return 0;
 }
 
