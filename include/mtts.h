@@ -244,6 +244,11 @@ int32_t mtts_codec_tokenize(MttsCodec* c, const float* dev_wav, const int32_t* h
  * bf16x3 kernel instead of the exact-f32 MFMA */
 int32_t mtts_k_gemm_f32(const float* dev_a, const float* dev_w, const float* dev_bias, float* dev_c,
                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* Tuning hook: time the decoder's pre-split bf16x3 GEMM (gemm_b3t_kernel) alone on synthetic operands.
+ * flags: 1 GELU | 2 gamma | 4 residual | 8 fragment-packed output (the decoder uses 0, 4, 6, 9); tile_code 0 = the
+ * production choice for the shape, else NA NB U OCC as decimal digits.  No reference counterpart. */
+int32_t mtts_k_gemm_planes_bench(int32_t M, int32_t N, int32_t K, int32_t flags, int32_t tile_code, int32_t iters,
+                                 float* avg_us, int32_t* code_used);
 
 #ifdef __cplusplus
 }

@@ -354,6 +354,73 @@ __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
     lo = (uint16_t)l;
 }
 
+// Epilogue of gemm_b3t_kernel.  D[n][row]: lane holds row = lane & 31 and n = 8q + 4(lane>>5) + j (register 4q + j).
+// Per element, in this order: + bias, GELU, * gamma, + residual; then fp32 float4 or the next GEMM's hi / lo planes.
+// The flags are template arguments so that a combination is straight-line code: the bias / gamma / residual loads of a
+// wave tile are issued ahead of the arithmetic instead of one exposed L2 round trip per 4 outputs behind a branch.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t v) {          // gelu_fast on a pair (packed fp32 multiply / fma)
+    const f32x2_t x = v * 0.70710678118654752440f;
+    const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2_t den = ax * 0.3275911f + 1.0f;
+    const f32x2_t t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};      // 1 ulp: inside the 7e-7 of the formula
+    const f32x2_t poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const f32x2_t ex = {__expf(-ax.x * ax.x), __expf(-ax.y * ax.y)};
+    const f32x2_t e = 1.0f - poly * ex;
+    const f32x2_t se = {copysignf(e.x, x.x), copysignf(e.y, x.y)};
+    return 0.5f * v * (1.0f + se);
+}
+
+template <int NA, int NB, bool ACT, bool GAMMA, bool RES, bool PLANES>
+__device__ __forceinline__ void b3t_epilogue(const GemmF32Args& g, f32x16_t (&acc)[NA][NB], int nt0, int rt0, int ntiles, int rtiles, int lane) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        if (nt0 + a >= ntiles) break;
+        const int nb = (nt0 + a) * 32 + 4 * (lane >> 5);
+        float4 bias[4], gam[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = min(nb + 8 * q, g.N - 4);                     // clamped: the load is unconditional, the store is not
+            bias[q] = g.bias ? *(const float4*)(g.bias + n) : zero4;
+            if (GAMMA) gam[q] = *(const float4*)(g.gamma + n);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (rt0 + b >= rtiles) break;
+            const int m = (rt0 + b) * 32 + (lane & 31);
+            const bool mok = m < g.M;
+            const int mc = min(m, g.M - 1);
+            float4 res[4];
+            if (RES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[q] = *(const float4*)(g.res + (long)mc * g.ldres + min(nb + 8 * q, g.N - 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 8 * q;
+                f32x2_t v0 = {acc[a][b][4 * q] + bias[q].x, acc[a][b][4 * q + 1] + bias[q].y};
+                f32x2_t v1 = {acc[a][b][4 * q + 2] + bias[q].z, acc[a][b][4 * q + 3] + bias[q].w};
+                if (ACT) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }
+                if (GAMMA) { v0 *= f32x2_t{gam[q].x, gam[q].y}; v1 *= f32x2_t{gam[q].z, gam[q].w}; }
+                if (RES) { v0 += f32x2_t{res[q].x, res[q].y}; v1 += f32x2_t{res[q].z, res[q].w}; }
+                if (mok && n < g.N) {
+                    if (PLANES) {
+                        uint32_t h0, l0, h1, l1;
+                        split2(v0.x, v0.y, h0, l0);
+                        split2(v1.x, v1.y, h1, l1);
+                        const size_t at = xpack_off(m, n, (int)g.ldc);
+                        *(u32x2_t*)(g.Chi + at) = u32x2_t{h0, h1};
+                        *(u32x2_t*)(g.Clo + at) = u32x2_t{l0, l1};
+                    } else {
+                        *(float4*)(g.C + (long)m * g.ldc + n) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // bf16x3 GEMM on pre-split operands in MFMA-FRAGMENT ORDER, no LDS (the layout of the AR engine's GEMMs, common.h):
 //   activations  [row/32][k/16][lane][8 bf16], lane = row%32 + 32*((k%16)/8)     (xpack_off; hi plane, then lo plane)
@@ -367,8 +434,8 @@ __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
 // ------------------------------------------------------------------------------------
 // NA x NB = 32-wide tiles per wave along n / along rows (a wave owns 32 NA columns x 32 NB rows, a block 2 x 2 waves);
 // U = k-steps per register set; OCC = waves per SIMD the register budget is cut for.
-//   <2,2,2,2>: 232 VGPRs, two waves per SIMD, 683 operand bytes per MFMA through the vector L1;  <2,2,1,3>: three waves;
-//   <4,2,1,2>: 512 bytes per MFMA;  <4,4,1,1>: 341 bytes per MFMA, one wave per SIMD (accumulators = 256 registers).
+//   <2,2,2,2>: 212 VGPRs, two waves per SIMD, 683 operand bytes per MFMA through the vector L1;  <2,3,1,2>: 569;
+//   <3,3,1,1>: 455, one wave per SIMD;  <4,3,1,1> / <3,4,1,1>: 398;  <4,4,1,1>: 341 (accumulators = 256 registers).
 // The vector L1 returns 64 B/clk per CU and the four matrix pipes of a CU retire one MFMA per 8 clk between them, so
 // 683 bytes per MFMA is L1-bound before it is MFMA-bound (measured: operand stream alone = 6.1 GB / 218 us = 64.7 B/clk/CU).
 template <int NA, int NB, int U, int OCC>
@@ -437,39 +504,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         compute(fb);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // D[n][row]: lane holds row = lane & 31 and n = 8q + 4(lane>>5) + j (register 4q + j)
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        if (nt0 + a >= ntiles) break;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (rt0 + b >= rtiles) break;
-            const int m = (rt0 + b) * 32 + (lane & 31);
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = (nt0 + a) * 32 + 8 * q + 4 * (lane >> 5);
-                if (n >= g.N) continue;                    // N is a multiple of 4 on this path
-                float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                if (g.bias) { const float4 t = *(const float4*)(g.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                if (g.act == 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
-                }
-                if (g.gamma) { const float4 t = *(const float4*)(g.gamma + n); v[0] *= t.x; v[1] *= t.y; v[2] *= t.z; v[3] *= t.w; }
-                if (g.res) { const float4 t = *(const float4*)(g.res + (long)m * g.ldres + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-                if (g.Chi) {
-                    uint32_t h0, l0, h1, l1;
-                    split2(v[0], v[1], h0, l0);
-                    split2(v[2], v[3], h1, l1);
-                    const size_t at = xpack_off(m, n, (int)g.ldc);
-                    *(u32x2_t*)(g.Chi + at) = u32x2_t{h0, h1};
-                    *(u32x2_t*)(g.Clo + at) = u32x2_t{l0, l1};
-                } else {
-                    *(float4*)(g.C + (long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
+    // one straight-line epilogue per combination the decoder uses (uniform switch, taken once)
+    const int combo = (g.act == 1) | (g.gamma ? 2 : 0) | (g.res ? 4 : 0) | (g.Chi ? 8 : 0);
+    switch (combo) {
+    case 0: b3t_epilogue<NA, NB, false, false, false, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;       // q/k/v
+    case 4: b3t_epilogue<NA, NB, false, false, true, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;        // out_proj, fc2
+    case 6: b3t_epilogue<NA, NB, false, true, true, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;         // Vocos pw2
+    case 9: b3t_epilogue<NA, NB, true, false, false, true>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;         // fc1, Vocos pw1
+    default: break;                                       // gemm_planes refuses any other combination
     }
 }
 
@@ -698,6 +740,75 @@ __global__ void im2col7_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 // ConvNeXt front: depthwise Conv1d(k=7, pad=3, groups=C) + bias + LayerNorm(eps) (modules.py:1139-1146).
 // dw is [7][C].  One wave per (b,t) row.
+// The same for C = 512 (Vocos), 8 consecutive rows per wave: a lane owns 8 consecutive channels (two float4 per row, one
+// 16-byte store per output plane), the 7 taps of its channels stay in registers and every input row is read once per
+// wave (14 rows for 8 outputs) instead of once per tap.  The convolution accumulates in the reference's tap order.
+__global__ __launch_bounds__(256) void dwconv_ln512_kernel(const float* __restrict__ h, const float* __restrict__ dw,
+                                                           const float* __restrict__ dwb, const float* __restrict__ lw,
+                                                           const float* __restrict__ lb, float* __restrict__ y, int B, int T,
+                                                           float eps, uint16_t* __restrict__ ylo) {
+    constexpr int C = 512, R = 8;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long rows = (long)B * T, r0 = ((long)blockIdx.x * 4 + wave) * R;
+    if (r0 >= rows) return;
+    const int c0 = lane * 8;
+    float win[R + 6][8];
+#pragma unroll
+    for (int i = 0; i < R + 6; ++i) {
+        const long r = r0 + i - 3;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (r >= 0 && r < rows) { a = *(const float4*)(h + r * C + c0); b = *(const float4*)(h + r * C + c0 + 4); }
+        win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w;
+        win[i][4] = b.x; win[i][5] = b.y; win[i][6] = b.z; win[i][7] = b.w;
+    }
+    float w[7][8], pb[8], g[8], be[8];
+    auto ld8 = [&](const float* p, float* o) {
+        const float4 a = *(const float4*)(p + c0), b = *(const float4*)(p + c0 + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    };
+#pragma unroll
+    for (int j = 0; j < 7; ++j) ld8(dw + j * C, w[j]);
+    ld8(dwb, pb); ld8(lw, g); ld8(lb, be);
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        const long row = r0 + o;
+        if (row >= rows) break;
+        const int t = (int)(row % T);
+        float v[8], s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = pb[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int ts = t + j - 3;
+            if (ts >= 0 && ts < T) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] += win[o + j][c] * w[j][c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s += v[c];
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float d = v[c] - mu; q += d * d; }
+        const float inv = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float ov[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ov[c] = (v[c] - mu) * inv * g[c] + be[c];
+        if (ylo) {
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split2(ov[2 * c], ov[2 * c + 1], hi[c], lo[c]);
+            const size_t at = xpack_off((int)row, c0, C);
+            *(u32x4_t*)((uint16_t*)y + at) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+            *(u32x4_t*)(ylo + at) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+        } else {
+            *(float4*)(y + row * C + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            *(float4*)(y + row * C + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ h, const float* __restrict__ dw,
                                                         const float* __restrict__ dwb, const float* __restrict__ lw,
                                                         const float* __restrict__ lb, float* __restrict__ y, int B, int T,
@@ -999,6 +1110,42 @@ static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
         if (_r) return _r;                          \
     } while (0)
 
+// Which tile shape: every variant computes the same bits (a tile only decides which wave owns an output element), so
+// the choice is free to follow the shape.  A CU holds one 4-wave block per wave-per-SIMD of the variant and runs its
+// share of the grid in sequence: time = ceil(blocks / 256) x (a KT + b + e [GELU epilogue]) with per-variant constants
+// fitted to a rocprofv3 sweep of all variants over the decoder's ten GEMM shapes (profiles/r02_codec_tile_sweep.json;
+// the model picks the measured-best variant on each of them).  Big tiles at one wave per SIMD need 341-455 operand
+// bytes per MFMA from the vector L1 instead of 683 and win wherever K is long (pw2 470 -> 269 us, fc2 314 -> 150 us);
+// 64 x 96 at two waves per SIMD wins the 512 -> 4096 expansion, whose time is its GELU / split / store epilogue.
+static int b3t_choose(int M, int N, int K, int act) {
+    struct Variant { int code, na, nb; double a, b, e; };
+    static const Variant variants[] = {{2222, 2, 2, 0.594, -3.5, 0.0}, {2312, 2, 3, 0.768, -2.1, -0.4}, {4221, 4, 2, 0.634, 9.6, 4.8},
+                                       {3311, 3, 3, 0.693, 12.5, 2.4}, {3411, 3, 4, 0.862, 13.0, 8.1}, {4311, 4, 3, 0.875, 12.8, 9.9},
+                                       {4411, 4, 4, 1.005, 25.9, 10.5}};
+    int code = 0;
+    double best = 1e30;
+    for (const Variant& v : variants) {
+        const long blocks = (long)((N + 64 * v.na - 1) / (64 * v.na)) * ((M + 64 * v.nb - 1) / (64 * v.nb));
+        const double t = (double)((blocks + 255) / 256) * (v.a * (K / 16) + v.b + (act == 1 ? v.e : 0.0));
+        if (t < best) { best = t; code = v.code; }
+    }
+    return code;
+}
+
+// code = NA NB U OCC as decimal digits
+static int b3t_launch(hipStream_t st, const GemmF32Args& g, int code) {
+    auto grid = [&](int na, int nb) { return dim3((g.N + 64 * na - 1) / (64 * na), (g.M + 64 * nb - 1) / (64 * nb), 1); };
+    switch (code) {
+#define MTTS_B3T(NA, NB, U, OCC) \
+    case NA * 1000 + NB * 100 + U * 10 + OCC: hipLaunchKernelGGL((gemm_b3t_kernel<NA, NB, U, OCC>), grid(NA, NB), dim3(256), 0, st, g); break;
+        MTTS_B3T(2, 2, 2, 2) MTTS_B3T(2, 3, 1, 2) MTTS_B3T(4, 2, 2, 1) MTTS_B3T(3, 3, 1, 1) MTTS_B3T(3, 4, 1, 1) MTTS_B3T(4, 3, 1, 1)
+        MTTS_B3T(4, 4, 1, 1)      // (2213, 2412, 2421, 3212, 3321, 4212 were in the sweep too: never the best, removed)
+#undef MTTS_B3T
+    default: return cfail(MTTS_EINVAL, "gemm_planes: no kernel for tile code %d", code);
+    }
+    return 0;
+}
+
 // C[M,N] = epi(A * W^T) on pre-split operands (gemm_b3t_kernel).  A: fragment-packed bf16 hi plane at `a_planes`, lo plane
 // pad32(M) rows further; W: the engine's fp32 weight, split + packed on first use.  Output: fp32 `C` (bias / GELU /
 // gamma / residual as gemm_f32) or, with c_planes, fragment-packed planes in the same buffer (the next GEMM's A).
@@ -1009,6 +1156,8 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
                        bool c_planes, long c_rows) {
     (void)a_rows; (void)c_rows; (void)lda;
     if (N % 4) return cfail(MTTS_EINVAL, "gemm_planes: N must be a multiple of 4");
+    const int combo = (act == 1) | (gamma ? 2 : 0) | (res ? 4 : 0) | (c_planes ? 8 : 0);          // the kernel's epilogues
+    if (combo != 0 && combo != 4 && combo != 6 && combo != 9) return cfail(MTTS_EINVAL, "gemm_planes: no epilogue for flag combination %d", combo);
     uint16_t* wp = nullptr;
     const long wn = pad32(N) * (long)K;                      // elements per weight plane
     auto it = k->wplanes.find(W);
@@ -1024,36 +1173,8 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
     GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
                   (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
                   c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
-    // Which tile shape: every variant computes the same bits (a tile only decides which wave owns an output element), so
-    // the choice is free to follow the shape.  A CU holds one 4-wave block per wave-per-SIMD of the variant and runs its
-    // share of the grid in sequence: time = ceil(blocks / 256) x (a KT + b + e [GELU epilogue]) with per-variant constants
-    // fitted to a rocprofv3 sweep of all variants over the decoder's ten GEMM shapes (profiles/r02_codec_tile_sweep.json;
-    // the model picks the measured-best variant on each of them).  Big tiles at one wave per SIMD need 341-455 operand
-    // bytes per MFMA from the vector L1 instead of 683 and win wherever K is long (pw2 470 -> 269 us, fc2 314 -> 150 us);
-    // 64 x 96 at two waves per SIMD wins the 512 -> 4096 expansion, whose time is its GELU / split / store epilogue.
-    struct Variant { int code, na, nb; double a, b, e; };
-    static const Variant variants[] = {{2222, 2, 2, 0.594, -3.5, 0.0}, {2312, 2, 3, 0.768, -2.1, -0.4}, {4221, 4, 2, 0.634, 9.6, 4.8},
-                                       {3311, 3, 3, 0.693, 12.5, 2.4}, {3411, 3, 4, 0.862, 13.0, 8.1}, {4311, 4, 3, 0.875, 12.8, 9.9},
-                                       {4411, 4, 4, 1.005, 25.9, 10.5}};
-    auto grid = [&](int na, int nb) { return dim3((N + 64 * na - 1) / (64 * na), (M + 64 * nb - 1) / (64 * nb), 1); };
-    int code = k->tile;                                  // NA NB U OCC as decimal digits (MTTS_CODEC_TILE forces one)
-    if (!code) {
-        double best = 1e30;
-        for (const Variant& v : variants) {
-            const dim3 gr = grid(v.na, v.nb);
-            const double t = (double)(((long)gr.x * gr.y + 255) / 256) * (v.a * (K / 16) + v.b + (act == 1 ? v.e : 0.0));
-            if (t < best) { best = t; code = v.code; }
-        }
-    }
-    switch (code) {
-#define MTTS_B3T(NA, NB, U, OCC) \
-    case NA * 1000 + NB * 100 + U * 10 + OCC: hipLaunchKernelGGL((gemm_b3t_kernel<NA, NB, U, OCC>), grid(NA, NB), dim3(256), 0, st, g); break;
-        MTTS_B3T(2, 2, 2, 2) MTTS_B3T(2, 2, 1, 3) MTTS_B3T(4, 4, 1, 1) MTTS_B3T(4, 3, 1, 1) MTTS_B3T(3, 4, 1, 1) MTTS_B3T(3, 3, 1, 1)
-        MTTS_B3T(4, 2, 2, 1) MTTS_B3T(2, 4, 2, 1) MTTS_B3T(3, 3, 2, 1) MTTS_B3T(3, 2, 1, 2) MTTS_B3T(2, 3, 1, 2) MTTS_B3T(4, 2, 1, 2)
-        MTTS_B3T(2, 4, 1, 2)
-#undef MTTS_B3T
-    default: return cfail(MTTS_EINVAL, "gemm_planes: no kernel for tile code %d", code);
-    }
+    int code = k->tile ? k->tile : b3t_choose(M, N, K, act);
+    TRYC(b3t_launch(st, g, code));
     return 0;
 }
 
@@ -1429,8 +1550,12 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
         NEED(p2_w, p + "pw2.w", (size_t)vd * vi); NEED(p2_b, p + "pw2.b", vd);
         NEED(gam, p + "gamma", vd);
         if (planes_ok(k, vd, vd) && planes_ok(k, vi, vi)) {
-            hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
-                               vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+            if (vd == 512)
+                hipLaunchKernelGGL(dwconv_ln512_kernel, dim3((rows8 + 31) / 32), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
+                                   1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+            else
+                hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
+                                   vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
             TRYC(gemm_planes(k, st, Cc, rows8, p1_w, k->big, rows8, vi, vd, vd, vi, p1_b, 1, nullptr, nullptr, 0, true, rows8));
             TRYC(gemm_planes(k, st, k->big, rows8, p2_w, A, rows8, vd, vi, vi, vd, p2_b, 0, gam, A, vd, false, 0));   // h += gamma * pw2(..)
             continue;
@@ -1588,6 +1713,53 @@ extern "C" int32_t mtts_codec_tokenize(MttsCodec* k, const float* dev_wav, const
     }
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(st));
+    return MTTS_OK;
+}
+
+// tuning hook: time gemm_b3t_kernel alone on synthetic operands.  flags: 1 GELU, 2 gamma, 4 residual, 8 planes out
+// (the decoder's combinations: 0, 4, 6, 9); tile_code 0 = the production choice.  avg_us over `iters` launches (HIP events).
+__global__ void fill_lcg_kernel(float* p, long n, unsigned seed, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    p[i] = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+}
+extern "C" int32_t mtts_k_gemm_planes_bench(int32_t M, int32_t N, int32_t K, int32_t flags, int32_t tile_code, int32_t iters,
+                                            float* avg_us, int32_t* code_used) {
+    if (M < 1 || N < 1 || K < 64 || K % 64 || N % 4 || iters < 1 || !avg_us) return cfail(MTTS_EINVAL, "gemm_planes_bench: bad argument");
+    if (flags != 0 && flags != 4 && flags != 6 && flags != 9) return cfail(MTTS_EINVAL, "gemm_planes_bench: no epilogue for flags %d", flags);
+    const long Mp = pad32(M), Np = pad32(N);
+    float *a32 = nullptr, *w32 = nullptr, *vecs = nullptr, *res = nullptr, *c = nullptr;
+    uint16_t *ap = nullptr, *wp = nullptr;
+    CHK(hipMalloc((void**)&a32, (size_t)M * K * 4)); CHK(hipMalloc((void**)&w32, (size_t)N * K * 4));
+    CHK(hipMalloc((void**)&ap, (size_t)Mp * K * 4)); CHK(hipMalloc((void**)&wp, (size_t)Np * K * 4));
+    CHK(hipMalloc((void**)&vecs, (size_t)N * 8)); CHK(hipMalloc((void**)&res, (size_t)M * N * 4)); CHK(hipMalloc((void**)&c, (size_t)Mp * N * 4));
+    CHK(hipMemset(ap, 0, (size_t)Mp * K * 4)); CHK(hipMemset(wp, 0, (size_t)Np * K * 4));
+    auto fill = [&](float* p, long n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_lcg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, p, n, seed, sc); };
+    fill(a32, (long)M * K, 1u, 1.0f); fill(w32, (long)N * K, 2u, 0.05f); fill(vecs, 2L * N, 3u, 1.0f); fill(res, (long)M * N, 4u, 1.0f);
+    hipLaunchKernelGGL(split_pack_w_kernel, dim3((unsigned)(((long)M * K + 255) / 256)), dim3(256), 0, nullptr, a32, ap, ap + Mp * K, M, K);
+    hipLaunchKernelGGL(split_pack_w_kernel, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, nullptr, w32, wp, wp + Np * K, N, K);
+    const bool planes = flags & 8;
+    GemmF32Args g{nullptr, nullptr, c, vecs, (flags & 2) ? vecs + N : nullptr, (flags & 4) ? res : nullptr, M, N, K, (long)K, (long)K, (long)N,
+                  (long)N, 0, 1.f, flags & 1, 1, 0, 0, 0, 0, 0, 0, ap, ap + Mp * K, wp, wp + Np * K,
+                  planes ? (uint16_t*)c : nullptr, planes ? (uint16_t*)c + Mp * N : nullptr};
+    const int code = tile_code ? tile_code : b3t_choose(M, N, K, flags & 1);
+    if (code_used) *code_used = code;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    TRYC(b3t_launch(nullptr, g, code));
+    TRYC(b3t_launch(nullptr, g, code));
+    CHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) TRYC(b3t_launch(nullptr, g, code));
+    CHK(hipEventRecord(e1, nullptr));
+    CHK(hipEventSynchronize(e1));
+    CHK(hipGetLastError());
+    float ms = 0.f;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.f / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a32); hipFree(w32); hipFree(ap); hipFree(wp); hipFree(vecs); hipFree(res); hipFree(c);
     return MTTS_OK;
 }
 

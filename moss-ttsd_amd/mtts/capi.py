@@ -94,6 +94,8 @@ _SIGS = {
     "mtts_codec_tokenize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_k_gemm_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),
+    "mtts_k_gemm_planes_bench": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 
 

@@ -10,4 +10,4 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-print(json.dumps(bench.codec_leg(torch.device("cuda:0"))))
+print(json.dumps(bench.codec_leg(torch.device("cuda:0"), reps=int(os.environ.get("MTTS_LEG_REPS", "3")))))
