@@ -150,3 +150,26 @@ def test_codec_decode_each_equals_per_sample_calls():
             rms = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
             assert rms <= 1e-6, (wpc, rms)
     eng.close()
+
+
+def test_codec_gemm_tile_variants_are_bit_identical(monkeypatch):
+    """gemm_b3t_kernel exists in seven tile shapes (64x64 .. 128x128 outputs per wave, one or two waves per SIMD) and
+    the host picks one per GEMM shape, so the choice changes with the number of windows in a call.  A tile shape only
+    decides which wave owns an output element: every variant must give the same bits.  Ragged lengths (rows not a
+    multiple of 32 or of any tile) through the whole decoder, each variant forced in turn (MTTS_CODEC_TILE)."""
+    from mtts.codec import CodecEngine
+    cfg = synth_codec.reduced(dec_layers=1, voc_layers=2)
+    w = synth_codec.synth_weights(cfg, 77)
+    rng = np.random.default_rng(78)
+    codes = [torch.from_numpy(rng.integers(0, 1024, (8, n))) for n in (13, 131, 375)]
+    outs = {}
+    for code in ("0", "2222", "2312", "4221", "3311", "3411", "4311", "4411"):
+        monkeypatch.setenv("MTTS_CODEC_TILE", code)
+        eng = CodecEngine(cfg)
+        eng.bind_state_dict(w)
+        outs[code] = [x.cpu().numpy() for x in eng.decode_each(codes)]
+        eng.close()
+    for code, got in outs.items():
+        for a, b in zip(outs["0"], got):
+            assert a.shape == b.shape and np.array_equal(a, b), code
+    assert all(np.isfinite(x).all() and float(np.abs(x).max()) > 0 for x in outs["0"])
