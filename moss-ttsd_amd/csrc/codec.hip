@@ -1031,6 +1031,7 @@ struct MttsCodec {
     // bf16 hi/lo planes of the constant weights (made on first use after binding): key = the engine's fp32 copy
     std::map<const float*, uint16_t*> wplanes;
     int planes = 1;             // pre-split fragment-packed operands for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
+    int attn_packed = 1;        // fused attention on K / V packed once per layer (MTTS_CODEC_ATTN_PACKED=0: split per wave and tile)
     int tile = 0;               // gemm_b3t_kernel: MTTS_CODEC_TILE = NA NB U OCC as digits forces one variant (0: per shape)
 };
 
@@ -1047,6 +1048,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
     if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
     if (const char* m = getenv("MTTS_CODEC_TILE")) k->tile = atoi(m);
+    if (const char* m = getenv("MTTS_CODEC_ATTN_PACKED")) k->attn_packed = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
@@ -1139,7 +1141,7 @@ static int b3t_launch(hipStream_t st, const GemmF32Args& g, int code) {
 #define MTTS_B3T(NA, NB, U, OCC) \
     case NA * 1000 + NB * 100 + U * 10 + OCC: hipLaunchKernelGGL((gemm_b3t_kernel<NA, NB, U, OCC>), grid(NA, NB), dim3(256), 0, st, g); break;
         MTTS_B3T(2, 2, 2, 2) MTTS_B3T(2, 3, 1, 2) MTTS_B3T(4, 2, 2, 1) MTTS_B3T(3, 3, 1, 1) MTTS_B3T(3, 4, 1, 1) MTTS_B3T(4, 3, 1, 1)
-        MTTS_B3T(4, 4, 1, 1)      // (2213, 2412, 2421, 3212, 3321, 4212 were in the sweep too: never the best, removed)
+        MTTS_B3T(4, 4, 1, 1)      // (2213, 2412, 2421, 3212, 3321, 3421, 4321, 4212 were measured too: never the best, removed)
 #undef MTTS_B3T
     default: return cfail(MTTS_EINVAL, "gemm_planes: no kernel for tile code %d", code);
     }
@@ -1195,6 +1197,8 @@ static int ensure_workspace(MttsCodec* k, int B, int T) {
     const int Tdec = T * up;
     const size_t ldT = ((size_t)Tdec + 15) / 16 * 16;
     size_t n_sc = (size_t)B * std::max(c.dec_heads, c.adapter_heads) * (size_t)Tdec * ldT;
+    // the fused attention parks K / V as four bf16 planes of 32-key tiles here (launch_codec_attn): 16 KiB per (b, head, tile)
+    n_sc = std::max(n_sc, (size_t)B * std::max(c.dec_heads, c.adapter_heads) * (((size_t)Tdec + 31) / 32) * 4096);
     CHK(hipMalloc((void**)&k->bufA, n_small * 4));
     CHK(hipMalloc((void**)&k->bufB, n_small * 4));
     CHK(hipMalloc((void**)&k->bufC, n_small * 4));
@@ -1365,6 +1369,187 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same attention on K / V operands split and laid out ONCE per layer (attn_pack_kv_kernel) instead of by every
+// wave for every key tile: per 32-key tile the kernel above spends ~200 of its ~400 VALU instructions per lane on the
+// fp32 -> bf16 hi / lo split of K and V and 32 four-byte V loads, against 24 MFMAs (768 clk): VALU-bound 2 : 1.
+// Per (b, head) and tile of 32 keys, 4 KiB per plane, MFMA-fragment order:
+//   K  [s4 = d/16][lane = key%32 + 32 ((d%16)/8)][8 d]                                     (A rows of S^T = K . Q^T)
+//   V^T [s2][t = d/32][lane = d%32 + 32 g][slot j <-> key 16 s2 + 4 g + (j&3) + 8 (j>>2)]    (A rows of O^T += V^T . P^T)
+// planes: K hi, K lo, V hi, V lo, `plane_elems` bf16 each; keys >= T are zero.  Same split, same products, same order
+// as codec_attn_kernel: identical bits.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_pack_kv_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ planes,
+                                                          size_t plane_elems, int T, int d, int tiles) {
+    const int tile = blockIdx.x, head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x, g = lane >> 5, ql = lane & 31;
+    const long ld = 3L * d;
+    const float* base = qkv + (long)b * T * ld + head * 64;
+    const size_t tb = (((size_t)b * gridDim.y + head) * tiles + tile) * 2048;
+    u32x4_t* Kh = (u32x4_t*)(planes + tb) + lane;
+    u32x4_t* Kl = (u32x4_t*)(planes + plane_elems + tb) + lane;
+    u32x4_t* Vh = (u32x4_t*)(planes + 2 * plane_elems + tb) + lane;
+    u32x4_t* Vl = (u32x4_t*)(planes + 3 * plane_elems + tb) + lane;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int key = tile * 32 + ql;
+        const float* kp = base + d + (long)min(key, T - 1) * ld + 8 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 a = key < T ? *(const float4*)(kp + 16 * s4) : z, c = key < T ? *(const float4*)(kp + 16 * s4 + 4) : z;
+            u32x4_t hi, lo;
+            split8(a, c, hi, lo);
+            Kh[s4 * 64] = hi;
+            Kl[s4 * 64] = lo;
+        }
+    }
+    const float* vrow = base + 2 * d + ql;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            auto at = [&](int j) {
+                const int key = tile * 32 + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2);
+                return key < T ? vrow[(long)key * ld + 32 * t] : 0.f;
+            };
+            u32x4_t hi, lo;
+            split8(make_float4(at(0), at(1), at(2), at(3)), make_float4(at(4), at(5), at(6), at(7)), hi, lo);
+            Vh[(s2 * 2 + t) * 64] = hi;
+            Vl[(s2 * 2 + t) * 64] = lo;
+        }
+}
+
+__global__ __launch_bounds__(256) void codec_attn_packed_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ planes,
+                                                                size_t plane_elems, int tiles, float* __restrict__ att,
+                                                                const int* __restrict__ lens, int T, int d, float scale,
+                                                                uint16_t* __restrict__ att_lo) {
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 5, ql = lane & 31;
+    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    if (blockIdx.x * 128 + wave * 32 >= T) return;
+    const int len = lens[b];
+    const bool qpad = q >= len;                         // padded (or out-of-range) query: uniform over all T keys
+    const long ld = 3L * d;
+    u32x4_t qh[4], qlo[4];
+    {
+        const float* qp = qkv + (long)b * T * ld + head * 64 + (long)min(q, T - 1) * ld + 8 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 a = *(const float4*)(qp + 16 * s4), c = *(const float4*)(qp + 16 * s4 + 4);
+            split8(a, c, qh[s4], qlo[s4]);
+        }
+    }
+    f32x16_t o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int kend = qpad ? T : len;                    // every lane of a wave needs keys up to the largest bound
+    int kmax = kend;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    const size_t hb = ((size_t)b * gridDim.y + head) * tiles * 256;          // in 16-byte units; a tile = 256 of them per plane
+    const u32x4_t* Kh = (const u32x4_t*)planes + hb + lane;
+    const u32x4_t* Kl = (const u32x4_t*)(planes + plane_elems) + hb + lane;
+    const u32x4_t* Vh = (const u32x4_t*)(planes + 2 * plane_elems) + hb + lane;
+    const u32x4_t* Vl = (const u32x4_t*)(planes + 3 * plane_elems) + hb + lane;
+    struct KV { u32x4_t kh[4], kl[4], vh[4], vl[4]; };
+    auto load = [&](KV& f, int tile) {
+        const size_t o4 = (size_t)min(tile, tiles - 1) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f.kh[i] = Kh[o4 + i * 64]; f.kl[i] = Kl[o4 + i * 64]; f.vh[i] = Vh[o4 + i * 64]; f.vl[i] = Vl[o4 + i * 64]; }
+    };
+    auto step = [&](KV& f, int k0) {
+        f32x16_t sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.kl[s4], *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.kh[s4], *(bf16x8_t*)&qlo[s4], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.kh[s4], *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
+        }
+        // masked scores of this lane's query: register i <-> key k0 + (i&3) + 8*(i>>2) + 4*g
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            float v = qpad ? 0.f : sacc[i] * scale;
+            if (key >= kend) v = -INFINITY;
+            sacc[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);    // no key yet: nothing to rescale
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = (sacc[i] == -INFINITY) ? 0.f : __expf(sacc[i] - m_new);
+            sacc[i] = pv;
+            ps += pv;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * corr + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[t][i] *= corr;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4_t ph, pl;
+            split8(make_float4(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3]),
+                   make_float4(sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]), ph, pl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.vl[s2 * 2 + t], *(bf16x8_t*)&ph, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.vh[s2 * 2 + t], *(bf16x8_t*)&pl, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.vh[s2 * 2 + t], *(bf16x8_t*)&ph, o[t], 0, 0, 0);
+            }
+        }
+    };
+    // two operand sets, ping-pong: the next tile's 16 KiB per wave are in flight under this tile's products and softmax
+    KV fa, fb;
+    load(fa, 0);
+    for (int k0 = 0; k0 < kmax; k0 += 64) {
+        load(fb, (k0 >> 5) + 1);
+        step(fa, k0);
+        if (k0 + 32 >= kmax) break;
+        load(fa, (k0 >> 5) + 2);
+        step(fb, k0 + 32);
+    }
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        const long ob = ((long)b * T + q) * d + head * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int col = head * 64 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (att_lo) {                                  // fragment-packed planes for the pre-split o_proj GEMM
+                    const size_t at = xpack_off(b * T + q, col, d);
+                    split1(o[t][i] * inv, ((uint16_t*)att)[at], att_lo[at]);
+                } else att[ob - head * 64 + col] = o[t][i] * inv;
+            }
+    }
+}
+
+// fused attention of one layer: K / V packed once into the (otherwise unused) score buffer, then the packed kernel
+static void launch_codec_attn(MttsCodec* k, hipStream_t st, const float* qkv, float* att, const int* d_lens, int B, int T, int d,
+                              int heads, uint16_t* att_lo) {
+    const float scale = 1.0f / sqrtf(64.f);
+    if (!k->attn_packed) {
+        hipLaunchKernelGGL(codec_attn_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, qkv, att, d_lens, T, d, scale, att_lo);
+        return;
+    }
+    const int tiles = (T + 31) / 32;
+    const size_t plane = (size_t)B * heads * tiles * 2048;               // 4 planes x 2 B <= B heads T ldT x 4 B of k->scores
+    hipLaunchKernelGGL(attn_pack_kv_kernel, dim3(tiles, heads, B), dim3(64), 0, st, qkv, (uint16_t*)k->scores, plane, T, d, tiles);
+    hipLaunchKernelGGL(codec_attn_packed_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, qkv, (const uint16_t*)k->scores,
+                       plane, tiles, att, d_lens, T, d, scale, att_lo);
+}
+
 // One pre-LN transformer layer (OmniWhisperTransformerLayer, modules.py:187-205) on x [B*T][d].
 static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p, float* x, float* tmp, float* qkv, float* att,
                              int B, int T, int d, int heads, int ffn, const int* d_lens) {
@@ -1383,8 +1568,7 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln1w, ln1b, tmp, rows, d, 1e-5f,
                            (const int*)nullptr, T, (long)d, tlo);
         TRYC(gemm_planes(k, st, tmp, rows, wqkv, qkv, rows, 3 * d, d, d, 3 * d, bqkv, 0, nullptr, nullptr, 0, false, 0));
-        hipLaunchKernelGGL(codec_attn_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, (const float*)qkv, att,
-                           d_lens, T, d, 1.0f / sqrtf((float)hd), (uint16_t*)att + pad32(rows) * d);
+        launch_codec_attn(k, st, qkv, att, d_lens, B, T, d, heads, (uint16_t*)att + pad32(rows) * d);
         TRYC(gemm_planes(k, st, att, rows, wo, x, rows, d, d, d, d, bo, 0, nullptr, x, d, false, 0));      // x += out_proj(att)
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln2w, ln2b, tmp, rows, d, 1e-5f,
                            (const int*)nullptr, T, (long)d, tlo);
@@ -1397,8 +1581,7 @@ static int transformer_layer(MttsCodec* k, hipStream_t st, const std::string& p,
     gemm_f32(st, false, tmp, wqkv, qkv, rows, 3 * d, d, d, d, 3 * d, bqkv);
     if (g_gemm_split && hd == 64) {
         // decode direction: one fused launch, the score matrix stays on chip
-        hipLaunchKernelGGL(codec_attn_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, (const float*)qkv, att,
-                           d_lens, T, d, 1.0f / sqrtf((float)hd));
+        launch_codec_attn(k, st, qkv, att, d_lens, B, T, d, heads, nullptr);
         gemm_f32(st, false, att, wo, x, rows, d, d, d, d, d, bo, 0, nullptr, x, d);          // x += out_proj(att)
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ln2w, ln2b, tmp, rows, d, 1e-5f,
                            (const int*)nullptr, T, (long)d);
