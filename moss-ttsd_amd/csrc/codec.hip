@@ -1121,12 +1121,23 @@ static int need(MttsCodec* k, const std::string& name, size_t n, float** out) {
 // 64 x 96 at two waves per SIMD wins the 512 -> 4096 expansion, whose time is its GELU / split / store epilogue.
 static int b3t_choose(int M, int N, int K, int act) {
     struct Variant { int code, na, nb; double a, b, e; };
-    static const Variant variants[] = {{2222, 2, 2, 0.594, -3.5, 0.0}, {2312, 2, 3, 0.768, -2.1, -0.4}, {4221, 4, 2, 0.634, 9.6, 4.8},
-                                       {3311, 3, 3, 0.693, 12.5, 2.4}, {3411, 3, 4, 0.862, 13.0, 8.1}, {4311, 4, 3, 0.875, 12.8, 9.9},
-                                       {4411, 4, 4, 1.005, 25.9, 10.5}};
+    // fitted at 8 windows per call (profiles/r02_codec_tile_sweep.json): the regime of long runs of tiles per CU
+    static const Variant big[] = {{2222, 2, 2, 0.594, -3.5, 0.0}, {2312, 2, 3, 0.768, -2.1, -0.4}, {4221, 4, 2, 0.634, 9.6, 4.8},
+                                  {3311, 3, 3, 0.693, 12.5, 2.4}, {3411, 3, 4, 0.862, 13.0, 8.1}, {4311, 4, 3, 0.875, 12.8, 9.9},
+                                  {4411, 4, 4, 1.005, 25.9, 10.5}};
+    // fitted over 1 / 2 / 4 / 8 windows per call (r02_codec_tile_sweep_small.json), with the 32- and 64-wide tiles that
+    // fill the chip when a call has few rows (fc2 of one window: 18 blocks of 128 x 128, 72 of 64 x 64)
+    static const Variant small[] = {{2222, 2, 2, 0.360, 8.1, -0.3}, {2312, 2, 3, 0.450, 10.8, 2.1}, {4221, 4, 2, 0.518, 14.8, 0.9},
+                                    {3311, 3, 3, 0.566, 13.7, 3.0}, {3411, 3, 4, 0.672, 16.3, 4.5}, {4311, 4, 3, 0.673, 17.4, 6.1},
+                                    {4411, 4, 4, 0.837, 22.8, 7.0}, {2122, 2, 1, 0.253, 3.7, -2.1}, {1222, 1, 2, 0.262, 3.4, -2.2},
+                                    {1122, 1, 1, 0.155, 1.5, -1.1}};
+    const bool large = (long)M * N >= (1L << 26);        // (the 512 -> 4096 expansion from 8 windows up: the second fit misjudges it)
+    const Variant* v0 = large ? big : small;
+    const int nv = large ? (int)(sizeof(big) / sizeof(big[0])) : (int)(sizeof(small) / sizeof(small[0]));
     int code = 0;
     double best = 1e30;
-    for (const Variant& v : variants) {
+    for (int i = 0; i < nv; ++i) {
+        const Variant& v = v0[i];
         const long blocks = (long)((N + 64 * v.na - 1) / (64 * v.na)) * ((M + 64 * v.nb - 1) / (64 * v.nb));
         const double t = (double)((blocks + 255) / 256) * (v.a * (K / 16) + v.b + (act == 1 ? v.e : 0.0));
         if (t < best) { best = t; code = v.code; }
@@ -1141,6 +1152,7 @@ static int b3t_launch(hipStream_t st, const GemmF32Args& g, int code) {
 #define MTTS_B3T(NA, NB, U, OCC) \
     case NA * 1000 + NB * 100 + U * 10 + OCC: hipLaunchKernelGGL((gemm_b3t_kernel<NA, NB, U, OCC>), grid(NA, NB), dim3(256), 0, st, g); break;
         MTTS_B3T(2, 2, 2, 2) MTTS_B3T(2, 3, 1, 2) MTTS_B3T(4, 2, 2, 1) MTTS_B3T(3, 3, 1, 1) MTTS_B3T(3, 4, 1, 1) MTTS_B3T(4, 3, 1, 1)
+        MTTS_B3T(2, 1, 2, 2) MTTS_B3T(1, 2, 2, 2) MTTS_B3T(1, 1, 2, 2)
         MTTS_B3T(4, 4, 1, 1)      // (2213, 2412, 2421, 3212, 3321, 3421, 4321, 4212 were measured too: never the best, removed)
 #undef MTTS_B3T
     default: return cfail(MTTS_EINVAL, "gemm_planes: no kernel for tile code %d", code);

@@ -153,7 +153,7 @@ def test_codec_decode_each_equals_per_sample_calls():
 
 
 def test_codec_gemm_tile_variants_are_bit_identical(monkeypatch):
-    """gemm_b3t_kernel exists in seven tile shapes (64x64 .. 128x128 outputs per wave, one or two waves per SIMD) and
+    """gemm_b3t_kernel exists in ten tile shapes (32x32 .. 128x128 outputs per wave, one or two waves per SIMD) and
     the host picks one per GEMM shape, so the choice changes with the number of windows in a call.  A tile shape only
     decides which wave owns an output element: every variant must give the same bits.  Ragged lengths (rows not a
     multiple of 32 or of any tile) through the whole decoder, each variant forced in turn (MTTS_CODEC_TILE)."""
@@ -163,7 +163,7 @@ def test_codec_gemm_tile_variants_are_bit_identical(monkeypatch):
     rng = np.random.default_rng(78)
     codes = [torch.from_numpy(rng.integers(0, 1024, (8, n))) for n in (13, 131, 375)]
     outs = {}
-    for code in ("0", "2222", "2312", "4221", "3311", "3411", "4311", "4411"):
+    for code in ("0", "2222", "2312", "4221", "3311", "3411", "4311", "4411", "2122", "1222", "1122"):
         monkeypatch.setenv("MTTS_CODEC_TILE", code)
         eng = CodecEngine(cfg)
         eng.bind_state_dict(w)
