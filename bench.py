@@ -468,6 +468,8 @@ def main():
                     out["end_to_end_overlapped"] = overlapped_leg(cfg, eng, device, ids, mask, T + (L - n_real), layers, 42)
             eng.close()
             out["codec_decode"] = codec_leg(device)
+            # process_batch hands the decoder up to 32 equal-length windows per call: the same leg at that size
+            out["codec_decode"]["ms_per_window_at_32_per_call"] = codec_leg(device, windows=32, reps=2)["ms_per_window"]
             if not args.no_cpu_baseline:
                 out["codec_decode"]["cpu_baseline"] = codec_cpu_baseline()
         if world == 1 and not args.no_cpu_baseline:
