@@ -13,6 +13,7 @@
 // Activations are token-major [rows = (window, frame)][channels]; every Linear /
 // Conv1d(k=1) / ConvTranspose1d is one GEMM with a fused epilogue.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -1389,7 +1390,8 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
 //   K  [s4 = d/16][lane = key%32 + 32 ((d%16)/8)][8 d]                                     (A rows of S^T = K . Q^T)
 //   V^T [s2][t = d/32][lane = d%32 + 32 g][slot j <-> key 16 s2 + 4 g + (j&3) + 8 (j>>2)]    (A rows of O^T += V^T . P^T)
 // planes: K hi, K lo, V hi, V lo, `plane_elems` bf16 each; keys >= T are zero.  Same split, same products, same order
-// as codec_attn_kernel: identical bits.
+// as codec_attn_kernel; the softmax runs in the log2 domain (one multiply less per score), so the two kernels agree
+// to rounding, not bit for bit.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void attn_pack_kv_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ planes,
                                                           size_t plane_elems, int T, int d, int tiles) {
@@ -1430,7 +1432,7 @@ __global__ __launch_bounds__(64) void attn_pack_kv_kernel(const float* __restric
         }
 }
 
-__global__ __launch_bounds__(256) void codec_attn_packed_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ planes,
+__global__ __launch_bounds__(256, 2) void codec_attn_packed_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ planes,
                                                                 size_t plane_elems, int tiles, float* __restrict__ att,
                                                                 const int* __restrict__ lens, int T, int d, float scale,
                                                                 uint16_t* __restrict__ att_lo) {
@@ -1471,7 +1473,14 @@ __global__ __launch_bounds__(256) void codec_attn_packed_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i) { f.kh[i] = Kh[o4 + i * 64]; f.kl[i] = Kl[o4 + i * 64]; f.vh[i] = Vh[o4 + i * 64]; f.vl[i] = Vl[o4 + i * 64]; }
     };
-    auto step = [&](KV& f, int k0) {
+    // a padded query row attends uniformly: its scores are 0 (scale 0), its key bound is T.  Scores live in the log2
+    // domain (scale * log2 e folded into one multiply, v_exp_f32 direct); pairs (v_pk_mul / v_pk_add) where possible.
+    const float scale2 = qpad ? 0.f : scale * 1.44269504088896340736f;
+    int kmin = kend;                                    // tiles that end at or before every lane's bound need no mask
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, __shfl_xor(kmin, off, 64));
+    auto step = [&](KV& f, int k0, auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
         f32x16_t sacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
@@ -1481,33 +1490,44 @@ __global__ __launch_bounds__(256) void codec_attn_packed_kernel(const float* __r
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.kh[s4], *(bf16x8_t*)&qlo[s4], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&f.kh[s4], *(bf16x8_t*)&qh[s4], sacc, 0, 0, 0);
         }
-        // masked scores of this lane's query: register i <-> key k0 + (i&3) + 8*(i>>2) + 4*g
-        float mx = -INFINITY;
+        // scores of this lane's query: register i <-> key k0 + (i&3) + 8*(i>>2) + 4*g.  exp2(-inf - m) = 0 does the
+        // masking of the tiles around the key bounds (tile 0 always holds a valid key: the running maximum is finite
+        // from then on).
+        f32x2_t v[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * g;
-            float v = qpad ? 0.f : sacc[i] * scale;
-            if (key >= kend) v = -INFINITY;
-            sacc[i] = v;
-            mx = fmaxf(mx, v);
+        for (int i = 0; i < 8; ++i) v[i] = f32x2_t{sacc[2 * i], sacc[2 * i + 1]} * scale2;
+        if (MASK) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (key >= kend) v[i >> 1][i & 1] = -INFINITY;
+            }
         }
+        float mx = fmaxf(v[0].x, v[0].y);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mx = fmaxf(fmaxf(mx, v[i].x), v[i].y);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float corr = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);    // no key yet: nothing to rescale
-        float ps = 0.f;
+        const float corr = (m_run == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: nothing to rescale
+        f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float pv = (sacc[i] == -INFINITY) ? 0.f : __expf(sacc[i] - m_new);
-            sacc[i] = pv;
-            ps += pv;
+        for (int i = 0; i < 8; ++i) {
+            const f32x2_t d2 = v[i] - m_new;
+            const f32x2_t p2 = {__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)};
+            sacc[2 * i] = p2.x; sacc[2 * i + 1] = p2.y;
+            ps2 += p2;
         }
+        float ps = ps2.x + ps2.y;
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * corr + ps;
         m_run = m_new;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[t][i] *= corr;
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2_t r = f32x2_t{o[t][i], o[t][i + 1]} * corr;
+                o[t][i] = r.x; o[t][i + 1] = r.y;
+            }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             u32x4_t ph, pl;
@@ -1524,12 +1544,19 @@ __global__ __launch_bounds__(256) void codec_attn_packed_kernel(const float* __r
     // two operand sets, ping-pong: the next tile's 16 KiB per wave are in flight under this tile's products and softmax
     KV fa, fb;
     load(fa, 0);
-    for (int k0 = 0; k0 < kmax; k0 += 64) {
+    int k0 = 0;
+    for (; k0 + 64 <= kmin; k0 += 64) {                 // tiles wholly inside every lane's key bound: no mask
         load(fb, (k0 >> 5) + 1);
-        step(fa, k0);
+        step(fa, k0, std::false_type{});
+        load(fa, (k0 >> 5) + 2);
+        step(fb, k0 + 32, std::false_type{});
+    }
+    for (; k0 < kmax; k0 += 64) {
+        load(fb, (k0 >> 5) + 1);
+        step(fa, k0, std::true_type{});
         if (k0 + 32 >= kmax) break;
         load(fa, (k0 >> 5) + 2);
-        step(fb, k0 + 32);
+        step(fb, k0 + 32, std::true_type{});
     }
     if (q < T) {
         const float inv = 1.0f / l_run;
