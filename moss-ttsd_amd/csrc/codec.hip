@@ -741,14 +741,15 @@ __global__ void im2col7_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 // ConvNeXt front: depthwise Conv1d(k=7, pad=3, groups=C) + bias + LayerNorm(eps) (modules.py:1139-1146).
 // dw is [7][C].  One wave per (b,t) row.
-// The same for C = 512 (Vocos), 8 consecutive rows per wave: a lane owns 8 consecutive channels (two float4 per row, one
+// The same for C = 512 (Vocos), R consecutive rows per wave: a lane owns 8 consecutive channels (two float4 per row, one
 // 16-byte store per output plane), the 7 taps of its channels stay in registers and every input row is read once per
-// wave (14 rows for 8 outputs) instead of once per tap.  The convolution accumulates in the reference's tap order.
+// wave (R + 6 rows for R outputs) instead of once per tap.  The convolution accumulates in the reference's tap order.
+template <int R>
 __global__ __launch_bounds__(256) void dwconv_ln512_kernel(const float* __restrict__ h, const float* __restrict__ dw,
                                                            const float* __restrict__ dwb, const float* __restrict__ lw,
                                                            const float* __restrict__ lb, float* __restrict__ y, int B, int T,
                                                            float eps, uint16_t* __restrict__ ylo) {
-    constexpr int C = 512, R = 8;
+    constexpr int C = 512;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long rows = (long)B * T, r0 = ((long)blockIdx.x * 4 + wave) * R;
     if (r0 >= rows) return;
@@ -1033,6 +1034,7 @@ struct MttsCodec {
     std::map<const float*, uint16_t*> wplanes;
     int planes = 1;             // pre-split fragment-packed operands for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
     int attn_packed = 1;        // fused attention on K / V packed once per layer (MTTS_CODEC_ATTN_PACKED=0: split per wave and tile)
+    int dw_rows = 4;            // dwconv_ln512_kernel: rows per wave (4: 31 us per launch at 8 windows; 8: 46 us, 2: 33 us)
     int tile = 0;               // gemm_b3t_kernel: MTTS_CODEC_TILE = NA NB U OCC as digits forces one variant (0: per shape)
 };
 
@@ -1049,6 +1051,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     if (const char* m = getenv("MTTS_CODEC_GEMM")) k->split_decode = strcmp(m, "f32") != 0;
     if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
     if (const char* m = getenv("MTTS_CODEC_TILE")) k->tile = atoi(m);
+    if (const char* m = getenv("MTTS_CODEC_DW_ROWS")) k->dw_rows = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_ATTN_PACKED")) k->attn_packed = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
@@ -1773,8 +1776,12 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
         NEED(gam, p + "gamma", vd);
         if (planes_ok(k, vd, vd) && planes_ok(k, vi, vi)) {
             if (vd == 512)
-                hipLaunchKernelGGL(dwconv_ln512_kernel, dim3((rows8 + 31) / 32), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
-                                   1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+                if (k->dw_rows == 4)
+                    hipLaunchKernelGGL(dwconv_ln512_kernel<4>, dim3((rows8 + 15) / 16), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
+                                       1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+                else
+                    hipLaunchKernelGGL(dwconv_ln512_kernel<8>, dim3((rows8 + 31) / 32), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
+                                       1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
             else
                 hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
                                    vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
