@@ -372,7 +372,7 @@ __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t v) {          // gelu_fast
     return 0.5f * v * (1.0f + se);
 }
 
-template <int NA, int NB, bool ACT, bool GAMMA, bool RES, bool PLANES>
+template <int NA, int NB, bool ACT, bool GAMMA, bool RES, bool PLANES, bool NT_OUT = false>
 __device__ __forceinline__ void b3t_epilogue(const GemmF32Args& g, f32x16_t (&acc)[NA][NB], int nt0, int rt0, int ntiles, int rtiles, int lane) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -411,8 +411,13 @@ __device__ __forceinline__ void b3t_epilogue(const GemmF32Args& g, f32x16_t (&ac
                         split2(v0.x, v0.y, h0, l0);
                         split2(v1.x, v1.y, h1, l1);
                         const size_t at = xpack_off(m, n, (int)g.ldc);
-                        *(u32x2_t*)(g.Chi + at) = u32x2_t{h0, h1};
-                        *(u32x2_t*)(g.Clo + at) = u32x2_t{l0, l1};
+                        if (NT_OUT) {
+                            __builtin_nontemporal_store(u32x2_t{h0, h1}, (u32x2_t*)(g.Chi + at));
+                            __builtin_nontemporal_store(u32x2_t{l0, l1}, (u32x2_t*)(g.Clo + at));
+                        } else {
+                            *(u32x2_t*)(g.Chi + at) = u32x2_t{h0, h1};
+                            *(u32x2_t*)(g.Clo + at) = u32x2_t{l0, l1};
+                        }
                     } else {
                         *(float4*)(g.C + (long)m * g.ldc + n) = make_float4(v0.x, v0.y, v1.x, v1.y);
                     }
@@ -511,7 +516,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     case 0: b3t_epilogue<NA, NB, false, false, false, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;       // q/k/v
     case 4: b3t_epilogue<NA, NB, false, false, true, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;        // out_proj, fc2
     case 6: b3t_epilogue<NA, NB, false, true, true, false>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;         // Vocos pw2
-    case 9: b3t_epilogue<NA, NB, true, false, false, true>(g, acc, nt0, rt0, ntiles, rtiles, lane); break;         // fc1, Vocos pw1
+    case 9:                                                                                                     // fc1, Vocos pw1
+        if (g.batch_inner == 2) b3t_epilogue<NA, NB, true, false, false, true, true>(g, acc, nt0, rt0, ntiles, rtiles, lane);
+        else b3t_epilogue<NA, NB, true, false, false, true>(g, acc, nt0, rt0, ntiles, rtiles, lane);
+        break;
     default: break;                                       // gemm_planes refuses any other combination
     }
 }
@@ -1034,6 +1042,7 @@ struct MttsCodec {
     std::map<const float*, uint16_t*> wplanes;
     int planes = 1;             // pre-split fragment-packed operands for the big decode-direction GEMMs (MTTS_CODEC_PLANES=0: off)
     int attn_packed = 1;        // fused attention on K / V packed once per layer (MTTS_CODEC_ATTN_PACKED=0: split per wave and tile)
+    int nt_out = 1;             // nontemporal stores of the GELU GEMMs' output planes (393 MB per Vocos pw1 launch: -1.3 % per window; MTTS_CODEC_NT_OUT=0: off)
     int dw_rows = 4;            // dwconv_ln512_kernel: rows per wave (4: 31 us per launch at 8 windows; 8: 46 us, 2: 33 us)
     int tile = 0;               // gemm_b3t_kernel: MTTS_CODEC_TILE = NA NB U OCC as digits forces one variant (0: per shape)
 };
@@ -1052,6 +1061,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     if (const char* m = getenv("MTTS_CODEC_PLANES")) k->planes = atoi(m) != 0;
     if (const char* m = getenv("MTTS_CODEC_TILE")) k->tile = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_DW_ROWS")) k->dw_rows = atoi(m);
+    if (const char* m = getenv("MTTS_CODEC_NT_OUT")) k->nt_out = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_ATTN_PACKED")) k->attn_packed = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
@@ -1192,6 +1202,7 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
                   (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
                   c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
     int code = k->tile ? k->tile : b3t_choose(M, N, K, act);
+    if (k->nt_out && combo == 9) g.batch_inner = 2;
     TRYC(b3t_launch(st, g, code));
     return 0;
 }
