@@ -72,6 +72,79 @@ __global__ __launch_bounds__(256) void k_packed(const u32x4_t* __restrict__ mant
     out[(size_t)pg * 64 + lane] = (unsigned short)(__builtin_bit_cast(unsigned, acc) >> 16);
 }
 
+
+// 13-bit variant, lossless in practice: 5-bit exponent offset = nibble plane + one bit plane [token][16 B]; planes
+// pre-arranged for cheap extraction (mantissa dword = [m0, m2, m1, m3]; nibble dword = values [0,2,4,6,1,3,5,7]; bit dword =
+// values [0,2,..,30 | 1,3,..,31]), so a pair costs and / shift-and / shift-or only.  G query heads share the page (GQA).
+template <int G>
+__global__ __launch_bounds__(256) void k_packed13(const u32x4_t* __restrict__ mant, const u32x4_t* __restrict__ expo,
+                                                  const u32x4_t* __restrict__ bits, const unsigned char* __restrict__ base, Q q,
+                                                  unsigned short* __restrict__ out, int npages) {
+    const int pg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pg >= npages) return;
+    const u32x4_t* pm = mant + (size_t)pg * 512 + lane;
+    const u32x4_t* pe = expo + (size_t)pg * 256 + lane;
+    u32x4_t m[8], x[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = __builtin_nontemporal_load(pm + j * 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __builtin_nontemporal_load(pe + j * 64);
+    const u32x4_t bw = __builtin_nontemporal_load(bits + (size_t)pg * 64 + lane);
+    const unsigned b = base[(size_t)pg * 64 + lane];
+    const unsigned base2 = b | (b << 16);
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+    const unsigned bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                  // 16 values: 4 mantissa dwords, 2 nibble dwords, half a bit dword
+        const unsigned mw[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
+        const unsigned ew[2] = {(j & 1) ? x[j >> 1].z : x[j >> 1].x, (j & 1) ? x[j >> 1].w : x[j >> 1].y};
+        const unsigned bd = bwv[j >> 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                          // pair h of mantissa dword c = pair (2c + h) of these 16 values
+                const int k = 2 * c + h;                           // pair index 0..7 within the 16 values
+                const unsigned P = (mw[c] >> (8 * h)) & 0x00ff00ffu;
+                const unsigned N2 = (ew[k >> 2] >> (4 * (k & 3))) & 0x000f000fu;
+                const unsigned B2 = (bd >> (8 * (j & 1) + k)) & 0x00010001u;
+                const unsigned off = N2 | (B2 << 4);
+                const unsigned w = (P & 0x007f007fu) | ((P & 0x00800080u) << 8) | ((base2 - off) << 7);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = dot2(w, q.w[(8 * j + k + 17 * g) & 63], acc[g]);
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) s += acc[g];
+    out[(size_t)pg * 64 + lane] = (unsigned short)(__builtin_bit_cast(unsigned, s) >> 16);
+}
+template <int G>
+__global__ __launch_bounds__(256) void k_plain_g(const u32x4_t* __restrict__ pages, Q q, unsigned short* __restrict__ out, int npages) {
+    const int pg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pg >= npages) return;
+    const u32x4_t* p = pages + (size_t)pg * 1024 + lane;
+    u32x4_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(p + j * 64);
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acc[g] = dot2(v[j].x, q.w[(4 * j + 17 * g) & 63], acc[g]); acc[g] = dot2(v[j].y, q.w[(4 * j + 1 + 17 * g) & 63], acc[g]);
+            acc[g] = dot2(v[j].z, q.w[(4 * j + 2 + 17 * g) & 63], acc[g]); acc[g] = dot2(v[j].w, q.w[(4 * j + 3 + 17 * g) & 63], acc[g]);
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) s += acc[g];
+    out[(size_t)pg * 64 + lane] = (unsigned short)(__builtin_bit_cast(unsigned, s) >> 16);
+}
+
 int main() {
     const int npages = 16384, copies = 6;
     std::vector<u32x4_t*> plain(copies), mant(copies), expo(copies);
@@ -101,6 +174,13 @@ int main() {
     run("bf16 pages (the engine's format)", npages * 16384 / 1e6, [&](int i) { hipLaunchKernelGGL(k_plain, grid, blk, 0, nullptr, plain[i], q, out, npages); });
     run("12-bit pages, unpacked in registers", npages * (8192 + 4096 + 64) / 1e6,
         [&](int i) { hipLaunchKernelGGL(k_packed, grid, blk, 0, nullptr, mant[i], expo[i], base[i], q, out, npages); });
+    std::vector<u32x4_t*> bitp(copies);
+    for (int i = 0; i < copies; ++i) { CK(hipMalloc((void**)&bitp[i], (size_t)npages * 1024)); CK(hipMemset(bitp[i], 0x11, (size_t)npages * 1024)); }
+    run("bf16 pages, 2 query heads (GQA)", npages * 16384 / 1e6, [&](int i) { hipLaunchKernelGGL(k_plain_g<2>, grid, blk, 0, nullptr, plain[i], q, out, npages); });
+    run("13-bit pages, 1 query head", npages * (8192 + 4096 + 1024 + 64) / 1e6,
+        [&](int i) { hipLaunchKernelGGL(k_packed13<1>, grid, blk, 0, nullptr, mant[i], expo[i], bitp[i], base[i], q, out, npages); });
+    run("13-bit pages, 2 query heads (GQA)", npages * (8192 + 4096 + 1024 + 64) / 1e6,
+        [&](int i) { hipLaunchKernelGGL(k_packed13<2>, grid, blk, 0, nullptr, mant[i], expo[i], bitp[i], base[i], q, out, npages); });
     CK(hipGetLastError());
     return 0;
 }
