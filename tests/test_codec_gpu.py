@@ -173,3 +173,16 @@ def test_codec_gemm_tile_variants_are_bit_identical(monkeypatch):
         for a, b in zip(outs["0"], got):
             assert a.shape == b.shape and np.array_equal(a, b), code
     assert all(np.isfinite(x).all() and float(np.abs(x).max()) > 0 for x in outs["0"])
+
+
+def test_gemm_planes_bench_hook_runs_every_variant():
+    """tools/gemm_planes_bench.py / gemm_planes_pmc.sh rest on mtts_k_gemm_planes_bench: every tile code and every epilogue
+    combination the decoder uses launches and reports a time; an unknown combination is refused."""
+    import ctypes as C
+    lib = capi.lib()
+    us, used = C.c_float(), C.c_int32()
+    for code in (0, 2222, 2312, 4221, 3311, 3411, 4311, 4411, 2122, 1222, 1122):
+        for flags in (0, 4, 6, 9):
+            assert lib.mtts_k_gemm_planes_bench(1000, 768, 256, flags, code, 2, C.byref(us), C.byref(used)) == 0
+            assert us.value > 0 and (code == 0 or used.value == code)
+    assert lib.mtts_k_gemm_planes_bench(1000, 768, 256, 3, 0, 2, C.byref(us), C.byref(used)) != 0
