@@ -1449,11 +1449,16 @@ __global__ __launch_bounds__(64) void attn_pack_kv_kernel(const float* __restric
 __global__ __launch_bounds__(256, 2) void codec_attn_packed_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ planes,
                                                                 size_t plane_elems, int tiles, float* __restrict__ att,
                                                                 const int* __restrict__ lens, int T, int d, float scale,
-                                                                uint16_t* __restrict__ att_lo) {
-    const int b = blockIdx.z, head = blockIdx.y;
+                                                                uint16_t* __restrict__ att_lo, int heads, int nqb, int groups) {
+    // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs: all query blocks of one (sequence, head) get the same
+    // id % 8, so its K / V planes (768 KiB at T = 1500) are pulled through ONE L2 instead of eight.
+    const int L = blockIdx.x, xcd = L & 7, sidx = L >> 3;
+    const int qb = sidx % nqb, gi = (sidx / nqb) * 8 + xcd;
+    if (gi >= groups) return;
+    const int b = gi / heads, head = gi - b * heads;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 5, ql = lane & 31;
-    const int q = blockIdx.x * 128 + wave * 32 + ql;
-    if (blockIdx.x * 128 + wave * 32 >= T) return;
+    const int q = qb * 128 + wave * 32 + ql;
+    if (qb * 128 + wave * 32 >= T) return;
     const int len = lens[b];
     const bool qpad = q >= len;                         // padded (or out-of-range) query: uniform over all T keys
     const long ld = 3L * d;
@@ -1476,7 +1481,7 @@ __global__ __launch_bounds__(256, 2) void codec_attn_packed_kernel(const float* 
     int kmax = kend;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
-    const size_t hb = ((size_t)b * gridDim.y + head) * tiles * 256;          // in 16-byte units; a tile = 256 of them per plane
+    const size_t hb = ((size_t)b * heads + head) * tiles * 256;               // in 16-byte units; a tile = 256 of them per plane
     const u32x4_t* Kh = (const u32x4_t*)planes + hb + lane;
     const u32x4_t* Kl = (const u32x4_t*)(planes + plane_elems) + hb + lane;
     const u32x4_t* Vh = (const u32x4_t*)(planes + 2 * plane_elems) + hb + lane;
@@ -1599,8 +1604,9 @@ static void launch_codec_attn(MttsCodec* k, hipStream_t st, const float* qkv, fl
     const int tiles = (T + 31) / 32;
     const size_t plane = (size_t)B * heads * tiles * 2048;               // 4 planes x 2 B <= B heads T ldT x 4 B of k->scores
     hipLaunchKernelGGL(attn_pack_kv_kernel, dim3(tiles, heads, B), dim3(64), 0, st, qkv, (uint16_t*)k->scores, plane, T, d, tiles);
-    hipLaunchKernelGGL(codec_attn_packed_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, st, qkv, (const uint16_t*)k->scores,
-                       plane, tiles, att, d_lens, T, d, scale, att_lo);
+    const int nqb = (T + 127) / 128, groups = B * heads;
+    hipLaunchKernelGGL(codec_attn_packed_kernel, dim3((unsigned)(((groups + 7) / 8) * 8 * nqb)), dim3(256), 0, st, qkv,
+                       (const uint16_t*)k->scores, plane, tiles, att, d_lens, T, d, scale, att_lo, heads, nqb, groups);
 }
 
 // One pre-LN transformer layer (OmniWhisperTransformerLayer, modules.py:187-205) on x [B*T][d].
