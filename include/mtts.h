@@ -108,10 +108,12 @@ int32_t mtts_weights_ready(MttsEngine* e);   /* 0 when every tensor is bound */
  * sampler[8], seed: sampling stream (Philox4x32-10).
  * Prefills the first T-7 slots, then runs the decode loop on the device until
  * every row is finished.  out: host_out_ids int64 [B, out_capacity, 8] receives
- * [B, T-7+G, 8]; *out_len = T-7+G.  G can exceed max_length - (T-7) by up to 14, exactly as in the reference
+ * [B, T-7+G, 8]; *out_len = T-7+G.  G can exceed max_length - (T-7), exactly as in the reference
  * (modeling_asteroid.py:140-141,165-168): a dialogue whose EOS falls within 7 steps of max_length still runs its
  * delay-pattern flush, and while it does, a row that was cut off by max_length is resurrected for a flush of its own
- * as soon as its channel-0 pick is not a speech token; size out_capacity as max_length + 14.
+ * as soon as its channel-0 pick is not a speech token (up to 14 steps past max_length); resurrections can chain, each
+ * further row adding up to 6 steps, so size out_capacity as max_length + 6 * B + 8.  The engine has room for the whole
+ * chain where max_seq_len allows and for 14 steps at least; a chain that outruns the room returns MTTS_ESTATE.
  * host_forced (verification hook, may be NULL): int64 [B, forced_len, 8] full
  * sequences; when given, every step's own decision is written to
  * host_decisions int64 [G,B,8] and the forced row is appended instead. */
@@ -141,6 +143,13 @@ int32_t mtts_read_logits_f32(MttsEngine* e, float* host_logits0, float* host_log
 int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSamplerCfg* sampler, void* stream);
 int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* host_ids, int32_t T, int32_t max_length, uint64_t seed,
                          void* stream);
+/* the same with an explicit Philox row id: the dialogue draws from (seed; step, row_id, channel) -- what row `row_id` of a
+ * static batch with that seed draws (mtts_slot_submit = row_id 0) */
+int32_t mtts_slot_submit_row(MttsEngine* e, int32_t slot, const int64_t* host_ids, int32_t T, int32_t max_length, uint64_t seed,
+                             int32_t row_id, void* stream);
+/* Philox row ids of the rows of the NEXT mtts_begin / mtts_generate (consumed by it; default 0..B-1): one rank's share of
+ * a sharded batch draws what its rows would draw inside the whole batch (host_row_ids int32 [n], n = that call's B). */
+int32_t mtts_set_row_ids(MttsEngine* e, const int32_t* host_row_ids, int32_t n);
 int32_t mtts_slot_states(MttsEngine* e, int32_t* host_state, void* stream);
 int32_t mtts_slot_read(MttsEngine* e, int32_t slot, int64_t* host_rows, int32_t capacity_steps, int32_t* n_steps);
 int32_t mtts_read_seq_state(MttsEngine* e, int32_t* host_nas, int32_t* host_unfinished, int32_t* host_kv_len, void* stream);
@@ -154,8 +163,13 @@ int32_t mtts_kv_pool_state(MttsEngine* e, int32_t* total_pages, int32_t* free_pa
 int32_t mtts_read_page_table(MttsEngine* e, int32_t* host_table, int32_t* host_n_pages);
 /* Forced replay mode of mtts_generate's verification hook: 0 (default) the forced row replaces the state machine's
  * output (replay of a greedy run); 1 it replaces the step's raw draw before the state machine, host_decisions receives
- * the raw draws (replay of a SAMPLED reference run: the state follows the reference's history). */
+ * the raw draws (replay of a SAMPLED reference run: the state follows the reference's history); 2 = as 1, and the forced
+ * row is also the raw draw of rows that max_length has cut off and that the reference keeps evaluating
+ * (modeling_asteroid.py:140-141: tests that script chained finished-row resurrections). */
 int32_t mtts_set_forced_mode(MttsEngine* e, int32_t as_draw);
+/* verification hook: the page table as the device holds it once everything queued on `stream` has run
+ * (host_table int32 [max_batch][max_pages_per_seq]); compare with mtts_read_page_table. */
+int32_t mtts_debug_read_device_page_table(MttsEngine* e, int32_t* host_table, void* stream);
 /* Frames first..first+n-1 as codec codes int64 [8][B][n] on the device (delay pattern undone, generation_utils.py:416-425);
  * `stream` must be ordered after the steps that produced frame first+n+6. */
 int32_t mtts_export_codes(MttsEngine* e, int32_t first, int32_t n, int64_t* dev_codes, void* stream);

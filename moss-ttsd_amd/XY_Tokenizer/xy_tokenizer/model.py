@@ -24,6 +24,17 @@ class XY_Tokenizer:
         self.device = torch.device("cpu")
 
     @classmethod
+    def from_engine_config(cls, cfg, state_dict, input_sample_rate, output_sample_rate, nq):
+        """A tokenizer from the engine-side config dict and a state dict that is already in memory (the ranks of a
+        sharded job that did not read the checkpoint: inference_sharded.load_model_sharded)."""
+        m = cls.__new__(cls)
+        m.cfg = dict(cfg)
+        m.input_sample_rate, m.output_sample_rate, m.nq = input_sample_rate, output_sample_rate, nq
+        m.encoder_downsample_rate, m.decoder_upsample_rate = 1280, 1920
+        m._sd, m._engine, m.device = state_dict, None, torch.device("cpu")
+        return m
+
+    @classmethod
     def load_from_checkpoint(cls, config_path: str, ckpt_path: str):
         with open(config_path) as f:
             config = yaml.safe_load(f)

@@ -87,7 +87,12 @@ void launch_f32_swiglu(const float* gu, float* act, int R, int I, hipStream_t st
 struct PageEdits { int32_t n; int32_t idx[31]; int32_t val[31]; };     // page-table entries handed over as launch arguments
 void launch_set_pages(int32_t* table, const PageEdits& ed, hipStream_t st);
 #define FLUSH_STEPS 7          // a dialogue whose EOS falls within 7 steps of max_length still runs its delay-pattern flush (modeling_asteroid.py:165-168)
-#define LINGER_STEPS 14        // static batch: a row finished BY max_length can be resurrected for a flush while another row's flush is still running (sampler.hip: update_kernel), so a batch may run up to 6 + 8 steps past max_length
+#define LINGER_STEPS 14        // static batch: a row finished BY max_length can be resurrected for a flush while another row's flush is still running (sampler.hip: update_kernel), so a batch runs up to 6 + 8 steps past max_length after ONE resurrection
+// Resurrections chain: a resurrected row's own 7-step flush keeps the batch alive, and every step of it re-tests the other
+// cut-off rows (modeling_asteroid.py:140-141,168), so each further row can add up to 6 more steps: 6 * B + 8 bounds the run.
+// Storage (token rows, KV pages, RoPE rows) is sized for that bound where the engine's max_seq_len leaves room, and for
+// LINGER_STEPS at least; a chain that outruns the room is reported (MTTS_ESTATE), never truncated silently.
+static inline int linger_bound(int B) { return 6 * B + 8; }
 
 // ---- errors -------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -151,6 +156,7 @@ struct MttsEngine {
     std::vector<char> slot_live;        // host's view: the slot holds a dialogue that may still step
     PageEdits pending_edits;            // table entries not yet on the device
     int forced_draw = 0;
+    std::vector<int32_t> next_row_ids;  // Philox row ids of the next mtts_begin (mtts_set_row_ids); empty = 0..B-1
     // ---- MTTS_DTYPE_F32 engine (f32path.hip): plain fp32 copies of everything, no packed layouts ----
     bool f32 = false;
     struct LayerF32 { float *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr, *ln_in = nullptr, *ln_post = nullptr, *qn = nullptr, *kn = nullptr; };
@@ -166,6 +172,7 @@ struct MttsEngine {
     RowMeta* d_meta = nullptr;          // decode rows
     LoopState* d_ls = nullptr;
     LoopState* h_ls = nullptr;          // pinned mirror
+    SeqState* h_seqs = nullptr;         // pinned mirror of d_seqs (mtts_sync_state)
     int32_t *d_decisions = nullptr, *d_cur = nullptr, *d_gen = nullptr, *d_declog = nullptr, *d_forced = nullptr,
             *d_tf = nullptr;
     uint32_t* d_bitmaps = nullptr;
@@ -272,6 +279,10 @@ static int pool_grow(MttsEngine* e, int b, int need, hipStream_t st) {
         e->free_pages.pop_back();
         const int at = b * e->max_pages + e->n_pages[b]++;
         e->h_page_table[at] = page;
+        // one batch is written by the lanes of ONE store (set_pages_kernel): an index must not appear twice in it
+        int dup = -1;
+        for (int i = 0; i < e->pending_edits.n; ++i) if (e->pending_edits.idx[i] == at) dup = i;
+        if (dup >= 0) { e->pending_edits.val[dup] = page; continue; }
         if (e->pending_edits.n == 31) TRY(pool_flush(e, st));
         e->pending_edits.idx[e->pending_edits.n] = at;
         e->pending_edits.val[e->pending_edits.n++] = page;
@@ -283,6 +294,14 @@ static int pool_grow(MttsEngine* e, int b, int need, hipStream_t st) {
 static void pool_release(MttsEngine* e, int b) {
     for (int i = e->n_pages[b] - 1; i >= 0; --i) e->free_pages.push_back(e->h_page_table[(size_t)b * e->max_pages + i]);
     e->n_pages[b] = 0;
+    // table entries of this slot that never reached the device (a grow that ended in MTTS_ENOMEM) are void now
+    int k = 0;
+    for (int i = 0; i < e->pending_edits.n; ++i)
+        if (e->pending_edits.idx[i] / e->max_pages != b) {
+            e->pending_edits.idx[k] = e->pending_edits.idx[i];
+            e->pending_edits.val[k++] = e->pending_edits.val[i];
+        }
+    e->pending_edits.n = k;
 }
 
 // ---- MTTS_DTYPE_F32 engine: allocation, binding, forward (kernels: f32path.hip) -------------------------------------
@@ -453,6 +472,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc(&e->d_ls, 1));
     HIPCHK(hipHostMalloc((void**)&e->h_ls, sizeof(LoopState)));
     memset(e->h_ls, 0, sizeof(LoopState));
+    HIPCHK(hipHostMalloc((void**)&e->h_seqs, MTTS_RCAP * sizeof(SeqState)));
     TRY(dalloc(&e->d_decisions, MTTS_RCAP * 8));
     TRY(dalloc(&e->d_cur, MTTS_RCAP * 8));
     TRY(dalloc(&e->d_tf, MTTS_RCAP * 7 * 8));
@@ -492,6 +512,7 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
                     e->d_pf_meta};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_ls) hipHostFree(e->h_ls);
+    if (e->h_seqs) hipHostFree(e->h_seqs);
     free_scratch(e->sscr);
     drop_graphs(e);
     if (e->cap_stream) hipStreamDestroy(e->cap_stream);
@@ -833,8 +854,8 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     if (max_length <= base) return fail(MTTS_EINVAL, "max_length %d leaves no room to generate (prompt slots %d)", max_length, base);
     // a dialogue whose EOS falls within 7 steps of max_length keeps stepping until its flush is through
     // (`unfinished | needs_additional_steps > 0`, modeling_asteroid.py:165-168)
-    const int max_steps = max_length - base + LINGER_STEPS;
-    e->B = B; e->T = T; e->base_length = base; e->max_length = max_length; e->max_steps = max_steps;
+    int max_steps = max_length - base + LINGER_STEPS;          // the least the engine must have room for; widened below
+    e->B = B; e->T = T; e->base_length = base; e->max_length = max_length;
     e->seed = seed; e->steps_issued = 0; e->has_forced = false;
     e->n_real.assign(B, 0);
     e->max_real = 0;
@@ -853,6 +874,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     // pages: every earlier run has been synchronised by its caller or is ordered before us on `st`; the prompts'
     // pages are taken now, the rest on demand as the dialogues grow (issue_steps)
     for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = b < B; }
+    e->pending_edits.n = 0;            // edits queued by a run that failed (MTTS_ENOMEM before its flush) belong to released pages
     for (int b = 0; b < B; ++b) {
         const int need = (e->n_real[b] + max_steps + MTTS_PAGE - 1) / MTTS_PAGE;
         if (need > e->max_pages) return fail(MTTS_ENOMEM, "row %d needs %d KV pages, a sequence holds at most %d (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
@@ -861,6 +883,10 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     TRY(pool_flush(e, st));
     if (e->max_real + max_steps > e->rope_rows)
         return fail(MTTS_EINVAL, "rope table has %d rows, need %d", e->rope_rows, e->max_real + max_steps);
+    // room for chained resurrections (linger_bound) as far as the page-table width and the RoPE table allow
+    max_steps = std::max(max_steps, std::min(max_length - base + linger_bound(B),
+                                             std::min(e->max_pages * MTTS_PAGE, e->rope_rows) - e->max_real));
+    e->max_steps = max_steps;
     // generation buffers
     TRY(ensure_gen_storage(e, max_steps));
     // flattened prefill rows; every dialogue starts on a 32-row tile boundary so that a tile holds consecutive
@@ -911,7 +937,11 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
                 }
         HIPCHK(hipMemcpyAsync(e->d_tf, tf.data(), tf.size() * 4, hipMemcpyHostToDevice, st));
         std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
-        for (int b = 0; b < B; ++b) ss[b] = SeqState{-1, 1, e->n_real[b], 0, base, max_length, b, 1, seed};
+        if (!e->next_row_ids.empty() && (int)e->next_row_ids.size() != B)
+            return fail(MTTS_EINVAL, "mtts_set_row_ids gave %d ids, the batch has %d rows", (int)e->next_row_ids.size(), B);
+        for (int b = 0; b < B; ++b)
+            ss[b] = SeqState{-1, 1, e->n_real[b], 0, base, max_length, e->next_row_ids.empty() ? b : e->next_row_ids[b], 1, seed};
+        e->next_row_ids.clear();
         HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
         LoopState ls{0, 0, 0, B, 0, e->gen_cap, e->forced_draw, e->f32 ? 1 : 0};
         e->continuous = false;
@@ -1022,13 +1052,14 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
     if (!e || !e->began) return fail(MTTS_ESTATE, "mtts_begin has not run");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->h_ls, e->d_ls, sizeof(LoopState), hipMemcpyDeviceToHost, S(stream)));
+    // (both copies ride the caller's stream into pinned memory: no null-stream copy that would serialise with the codec leg)
+    if (!e->continuous) HIPCHK(hipMemcpyAsync(e->h_seqs, e->d_seqs, e->B * sizeof(SeqState), hipMemcpyDeviceToHost, S(stream)));
     HIPCHK(hipStreamSynchronize(S(stream)));
     if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 4096 candidate tokens (set top_k so that the k-th score's radix bin holds <= 4096 tokens)", e->h_ls->error);
     if (!e->continuous) {
         // static batch (mtts_generate semantics): a finished row only emits padding from here on and never touches
         // its KV pages again; everything issued so far has completed, so its pages go back to the pool
-        std::vector<SeqState> ss(e->B);
-        HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
+        const SeqState* ss = e->h_seqs;
         for (int b = 0; b < e->B; ++b)
             if (e->slot_live[b] && ss[b].step > 0 && !ss[b].unfinished && ss[b].active != 2) { e->slot_live[b] = 0; pool_release(e, b); }
     }
@@ -1118,6 +1149,10 @@ int32_t mtts_generate(MttsEngine* e, const int64_t* ids, const uint8_t* mask, in
         TRY(mtts_sync_state(e, &steps, &done, stream));
     }
     TRY(mtts_sync_state(e, &steps, &done, stream));
+    if (!forced && !done)
+        return fail(MTTS_ESTATE, "the batch is still flushing after %d steps (%d past max_length): chained finished-row "
+                    "resurrections (modeling_asteroid.py:140-141,168) outran the room max_seq_len %d leaves; raise it by %d",
+                    steps, steps - (max_length - base), e->cfg.max_seq_len, linger_bound(B) - LINGER_STEPS);
     const int total = base + steps;
     if (total > out_capacity) return fail(MTTS_EINVAL, "out_capacity %d < %d", out_capacity, total);
     std::vector<int64_t> gen((size_t)std::max(steps, 1) * B * 8);
@@ -1168,6 +1203,7 @@ int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSam
     e->max_real = 0;
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = 0; }
+    e->pending_edits.n = 0;
     std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
     HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
     LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, e->f32 ? 1 : 0};
@@ -1189,6 +1225,20 @@ int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSam
 // host_ids int64 [T][8] (one delay-shifted prompt, no padding), max_length in its own padded-slot units (T + max_new).
 int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_t T, int32_t max_length, uint64_t seed,
                          void* stream) {
+    return mtts_slot_submit_row(e, slot, ids, T, max_length, seed, 0, stream);
+}
+
+// Philox row ids for the rows of the NEXT mtts_begin / mtts_generate (consumed by it): row b draws from counter
+// (step, host_row_ids[b], channel, 0).  Default 0..B-1.  Lets one rank's share of a sharded batch, or one chunk of a
+// large one, draw exactly what its rows would draw inside the whole batch.
+int32_t mtts_set_row_ids(MttsEngine* e, const int32_t* host_row_ids, int32_t n) {
+    if (!e || (n > 0 && !host_row_ids) || n < 0 || n > MTTS_RCAP) return fail(MTTS_EINVAL, "set_row_ids: bad argument");
+    e->next_row_ids.assign(host_row_ids, host_row_ids + n);
+    return MTTS_OK;
+}
+
+int32_t mtts_slot_submit_row(MttsEngine* e, int32_t slot, const int64_t* ids, int32_t T, int32_t max_length, uint64_t seed,
+                             int32_t row_id, void* stream) {
     if (!e || !e->began || !e->continuous || !ids) return fail(MTTS_ESTATE, "mtts_sched_open has not run");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = S(stream);
@@ -1256,7 +1306,7 @@ int32_t mtts_slot_submit(MttsEngine* e, int32_t slot, const int64_t* ids, int32_
     HIPCHK(hipMemcpyAsync((uint16_t*)e->logits0 + (size_t)slot * e->V0_pad, e->join_logits0, (size_t)e->V0 * 2, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync((uint16_t*)e->logits17 + (size_t)slot * 7 * e->Vs_pad, e->join_logits17, (size_t)7 * e->Vs_pad * 2, hipMemcpyDeviceToDevice, st));
     }
-    SeqState ns{-1, 1, n, 0, base, max_length, 0, 1, seed};
+    SeqState ns{-1, 1, n, 0, base, max_length, row_id, 1, seed};
     HIPCHK(hipMemcpyAsync(e->d_seqs + slot, &ns, sizeof(ns), hipMemcpyHostToDevice, st));
     int32_t zero = 0;
     HIPCHK(hipMemcpyAsync(&e->d_ls->done, &zero, 4, hipMemcpyHostToDevice, st));
@@ -1314,9 +1364,20 @@ int32_t mtts_read_page_table(MttsEngine* e, int32_t* host_table, int32_t* host_n
     return MTTS_OK;
 }
 
+// verification hook: the page table as the DEVICE holds it (after everything queued on `stream`)
+int32_t mtts_debug_read_device_page_table(MttsEngine* e, int32_t* host_table, void* stream) {
+    if (!e || !host_table) return fail(MTTS_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    TRY(pool_flush(e, S(stream)));
+    HIPCHK(hipMemcpyAsync(host_table, e->d_page_table, e->h_page_table.size() * 4, hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return MTTS_OK;
+}
+
 int32_t mtts_set_forced_mode(MttsEngine* e, int32_t as_draw) {
     if (!e) return fail(MTTS_EINVAL, "null engine");
-    e->forced_draw = as_draw ? 1 : 0;
+    if (as_draw < 0 || as_draw > 2) return fail(MTTS_EINVAL, "forced mode must be 0, 1 or 2");
+    e->forced_draw = as_draw;
     return MTTS_OK;
 }
 

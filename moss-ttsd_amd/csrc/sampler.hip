@@ -37,7 +37,7 @@ struct LoopState {          // one per engine, device resident
     int32_t B;
     int32_t error;          // sticky device-side error
     int32_t gen_cap;        // rows of generated-token storage per slot
-    int32_t forced_draw;    // forced replay: 1 = the forced row replaces the step's raw draw BEFORE the state machine
+    int32_t forced_draw;    // forced replay: 1 (2: cut-off rows too) = the forced row replaces the step's raw draw BEFORE the state machine
                             //    (replay of a sampled reference run); 0 = it replaces the state machine's output
     int32_t logits_f32;     // the logits buffers hold fp32 (MTTS_DTYPE_F32 engine) instead of bf16
 };
@@ -530,7 +530,9 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
                 for (int c = 0; c < 8; ++c) {
                     dec_log[slot + c] = tok[c];
                     const int f = forced[slot + c];
-                    if (f >= 0 && s.unfinished) tok[c] = f;
+                    // (mode 2, tests of chained resurrections: the forced row is also the raw draw of a cut-off row that
+                    //  the reference keeps evaluating -- a real reference run does not record those draws)
+                    if (f >= 0 && (s.unfinished || (linger && ls->forced_draw == 2))) tok[c] = f;
                 }
             }
             // :140-141

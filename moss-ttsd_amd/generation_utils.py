@@ -252,10 +252,13 @@ def normalize_text(text: str) -> str:
 
 
 # ---- the batch API -------------------------------------------------------------------------
-def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, start_idx, use_normalize=False):
-    """-> (actual_texts_data, audio_results); a failed sample yields None, a batch-level failure re-raises."""
+def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, start_idx, use_normalize=False, indices=None):
+    """-> (actual_texts_data, audio_results); a failed sample yields None, a batch-level failure re-raises.
+    `indices` (not in the reference; used by inference_sharded.process_batch_sharded): the job-wide index of each item
+    when this call serves one rank's share of a larger batch; default start_idx + position, as in the reference."""
     try:
         n = len(batch_items)
+        gidx = [start_idx + i for i in range(n)] if indices is None else [int(x) for x in indices]
         print(f"Processing {n} samples starting from index {start_idx}...")
         texts, audios, meta = [], [], []
         for i, item in enumerate(batch_items):
@@ -265,7 +268,7 @@ def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, sta
             final = full.replace("[S1]", "<speaker1>").replace("[S2]", "<speaker2>")
             texts.append(final)
             audios.append(it["prompt_audio"])
-            meta.append({"index": start_idx + i, "original_text": original,
+            meta.append({"index": gidx[i], "original_text": original,
                          "normalized_text": normalize_text(original) if use_normalize else None,
                          "final_text": final, "use_normalize": use_normalize})
         seqs = []
@@ -288,15 +291,15 @@ def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, sta
         valid = []
         for i in range(n):
             if int(last[i]) + 1 <= 0:
-                print(f"Sample {start_idx + i} has no valid speech tokens")
+                print(f"Sample {gidx[i]} has no valid speech tokens")
             else:
                 valid.append(i)
-                print(f"Speech token shape for sample {start_idx + i}: {speech_ids[i, :int(last[i]) + 1].shape}")
+                print(f"Speech token shape for sample {gidx[i]}: {speech_ids[i, :int(last[i]) + 1].shape}")
 
         def pack(i, wav):
             wav = wav.cpu().detach()
             return {"audio_data": wav.unsqueeze(0) if wav.ndim == 1 else wav,
-                    "sample_rate": spt.output_sample_rate, "index": start_idx + i}
+                    "sample_rate": spt.output_sample_rate, "index": gidx[i]}
 
         # The reference decodes one sample per spt.decode call (generation_utils.py:434-450).  Here the 30 s windows
         # of ALL samples go through the codec together, each exactly as in its own call (`decode_each`: only windows
@@ -314,9 +317,9 @@ def process_batch(batch_items, tokenizer, model, spt, device, system_prompt, sta
                 wav = wavs[k] if wavs is not None else \
                     spt.decode([speech_ids[i, :int(last[i]) + 1].permute(1, 0)], overlap_seconds=10)["syn_wav_list"][0]
                 results[i] = pack(i, wav)
-                print(f"Audio generation completed: sample {start_idx + i}")
+                print(f"Audio generation completed: sample {gidx[i]}")
             except Exception as e:
-                print(f"Error processing sample {start_idx + i}: {str(e)}, skipping...")
+                print(f"Error processing sample {gidx[i]}: {str(e)}, skipping...")
                 traceback.print_exc()
                 results[i] = None
         return meta, results

@@ -115,6 +115,8 @@ class AsteroidTTSInstruct:
         self.training = False
         self.dtype = "bf16"             # "fp32": the strict-parity engine (from_pretrained(torch_dtype=torch.float32))
         self.sample_seed = None         # explicit Philox key for the next generate() (tests); None = from torch's seed
+        self.sample_rows = None         # Philox row id of each row of the next generate() (a rank's share of a sharded
+                                        # batch sets its rows' job-wide positions); None = 0..B-1
         self._calls = 0
 
     # ---- loading -----------------------------------------------------------------
@@ -183,12 +185,17 @@ class AsteroidTTSInstruct:
         seed = self._next_seed(seed)
         ids = input_ids.detach().cpu().numpy()
         msk = attention_mask.detach().cpu().numpy()
-        eng = self._get_engine(B, int(max_length) + 14)
+        rows = list(range(B)) if self.sample_rows is None else [int(r) for r in self.sample_rows]
+        if len(rows) != B:
+            raise ValueError(f"sample_rows has {len(rows)} entries for a batch of {B}")
+        # room for the reference's finished-row flushes past max_length: 14 steps at least, the whole chain
+        # (6 * B + 8, include/mtts.h: mtts_generate) where that is cheap
+        eng = self._get_engine(B, int(max_length) + 6 * min(B, self.MAX_ENGINE_BATCH) + 8)
         if B <= self.MAX_ENGINE_BATCH:
             # one static batch, the reference's semantics: finished rows emit (eos, 1024 x 7) until the batch ends
-            out = eng.generate(ids, msk, int(max_length), layers=layers, do_samples=do_samples, seed=seed)
+            out = eng.generate(ids, msk, int(max_length), layers=layers, do_samples=do_samples, seed=seed, row_ids=rows)
         else:
-            out = self._generate_scheduled(eng, ids, msk, int(max_length), layers, do_samples, seed)
+            out = self._generate_scheduled(eng, ids, msk, int(max_length), layers, do_samples, seed, rows)
         return torch.from_numpy(out).to(input_ids.device)
 
     def _next_seed(self, seed):
@@ -203,9 +210,13 @@ class AsteroidTTSInstruct:
         self._calls += 1
         return int(seed)
 
-    def _generate_scheduled(self, eng, ids, msk, max_length, layers, do_samples, seed):
+    def _generate_scheduled(self, eng, ids, msk, max_length, layers, do_samples, seed, rows):
         """More rows than one pass carries: the continuous batcher serves them through MAX_ENGINE_BATCH slots (a
-        finished dialogue's slot and KV pages go to the next one).  Row i draws from the Philox key seed + i."""
+        finished dialogue's slot and KV pages go to the next one).  Row i draws from the Philox stream
+        (seed; step, rows[i], channel) -- the stream row i of one static batch would use, so the same seed and prompts
+        give the same tokens on either side of the 128-row limit (what differs: a dialogue cut off by max_length leaves
+        at once here, while the reference keeps evaluating it and may resurrect it for a flush while another row is
+        still flushing, modeling_asteroid.py:140-141,168)."""
         from mtts.scheduler import ContinuousBatcher
         B, T, C = ids.shape
         base = T - 7
@@ -214,7 +225,7 @@ class AsteroidTTSInstruct:
         new = max_length - T
         cb = ContinuousBatcher(eng, slots=self.MAX_ENGINE_BATCH, gen_cap=max_length - base + 8, layers=layers,   # max_new + 7 flush steps
                                do_samples=do_samples)
-        res = cb.run(prompts, new, base_seed=seed)
+        res = cb.run(prompts, new, seeds=[seed] * B, row_ids=rows)
         G = max(r.shape[0] - (T - pads[b] - 7) for b, r in enumerate(res))
         full = np.full((B, base + G, C), self.config.speech_pad_token, dtype=np.int64)
         full[:, :, 0] = self.config.eos_token_id            # finished-row padding (modeling_asteroid.py:155-158)

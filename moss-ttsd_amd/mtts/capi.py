@@ -63,6 +63,8 @@ _SIGS = {
     "mtts_read_logits_f32": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_sched_open": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(MttsSamplerCfg), C.c_void_p]),
     "mtts_slot_submit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
+    "mtts_slot_submit_row": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
+    "mtts_set_row_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mtts_slot_states": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_slot_read": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "mtts_read_seq_state": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -70,6 +72,7 @@ _SIGS = {
     "mtts_kv_pool_state": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mtts_read_page_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_set_forced_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mtts_debug_read_device_page_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_export_codes": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mtts_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mtts_profile_read": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),

@@ -105,19 +105,28 @@ class Engine:
         assert ids.ndim == 3 and ids.shape[2] == 8 and m.shape == ids.shape[:2]
         return ids, m
 
+    def _set_row_ids(self, row_ids, B):
+        if row_ids is not None:
+            r = np.ascontiguousarray(row_ids, dtype=np.int32)
+            assert r.shape == (B,)
+            capi.check(self.lib.mtts_set_row_ids(self._h, r.ctypes.data, B))
+
     def generate(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0, forced=None,
-                 forced_as_draw=False):
+                 forced_as_draw=False, row_ids=None):
         """forced (verification hook): int64 [B,G,8] full sequences of a reference run.  -> (ids, decisions [steps,B,8]).
         forced_as_draw: the forced row replaces each step's raw draw before the state machine (replay of a SAMPLED
-        run); decisions are then the raw draws."""
+        run); decisions are then the raw draws.  forced_as_draw="all": also for rows that max_length has cut off (the
+        reference keeps evaluating them; scripted tests of chained resurrections)."""
         ids, m = self._host_inputs(input_ids, attention_mask)
         B, T, _ = ids.shape
-        cap = int(max_length) + 14         # flushes that start at / run past max_length (include/mtts.h: mtts_generate)
+        cap = int(max_length) + 6 * B + 8  # flushes that start at / run past max_length, chained (include/mtts.h: mtts_generate)
         self._B = B
-        capi.check(self.lib.mtts_set_forced_mode(self._h, 1 if (forced is not None and forced_as_draw) else 0))
+        mode = 0 if (forced is None or not forced_as_draw) else (2 if forced_as_draw == "all" else 1)
+        capi.check(self.lib.mtts_set_forced_mode(self._h, mode))
         out = np.zeros((B, cap, 8), dtype=np.int64)
         out_len = C.c_int32(0)
         scfg = sampler_cfgs(layers, do_samples)
+        self._set_row_ids(row_ids, B)       # Philox row id of each row (default: its position in this batch)
         fptr, flen, dptr, dec = None, 0, None, None
         if forced is not None:
             forced = np.ascontiguousarray(forced, dtype=np.int64)
@@ -132,10 +141,11 @@ class Engine:
             return res, dec[:out_len.value - (T - 7)].copy()
         return res
 
-    def begin(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0):
+    def begin(self, input_ids, attention_mask, max_length, layers=None, do_samples=None, seed=0, row_ids=None):
         ids, m = self._host_inputs(input_ids, attention_mask)
         B, T, _ = ids.shape
         self._B, self._T = B, T
+        self._set_row_ids(row_ids, B)
         capi.check(self.lib.mtts_begin(self._h, ids.ctypes.data, m.ctypes.data, B, T, int(max_length),
                                        sampler_cfgs(layers, do_samples), C.c_uint64(seed), None))
 
@@ -173,12 +183,13 @@ class Engine:
         self._B = int(slots)
         capi.check(self.lib.mtts_sched_open(self._h, int(slots), int(gen_cap), sampler_cfgs(layers, do_samples), None))
 
-    def submit(self, slot, ids, max_length, seed=0):
-        """ids int64 [T,8]: one delay-shifted prompt without padding (what shifting_inputs returns)."""
+    def submit(self, slot, ids, max_length, seed=0, row_id=0):
+        """ids int64 [T,8]: one delay-shifted prompt without padding (what shifting_inputs returns).  The dialogue
+        draws from the Philox stream (seed; step, row_id, channel)."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         assert ids.ndim == 2 and ids.shape[1] == 8
-        capi.check(self.lib.mtts_slot_submit(self._h, int(slot), ids.ctypes.data, ids.shape[0], int(max_length),
-                                             C.c_uint64(seed), None))
+        capi.check(self.lib.mtts_slot_submit_row(self._h, int(slot), ids.ctypes.data, ids.shape[0], int(max_length),
+                                                 C.c_uint64(seed), int(row_id), None))
 
     def slot_states(self):
         """-> int32 [slots,4]: active, unfinished, rows generated, tokens cached."""
@@ -209,6 +220,13 @@ class Engine:
         n = np.zeros(int(max_batch), dtype=np.int32)
         capi.check(self.lib.mtts_read_page_table(self._h, t.ctypes.data, n.ctypes.data))
         return t, n
+
+    def device_page_table(self, max_batch):
+        """The page table as the device holds it (verification hook) -> int32 [max_batch, pages per row]."""
+        _, _, mp = self.kv_pool_state()
+        t = np.zeros((int(max_batch), mp), dtype=np.int32)
+        capi.check(self.lib.mtts_debug_read_device_page_table(self._h, t.ctypes.data, None))
+        return t
 
     def seq_state(self):
         """-> (needs_additional_steps[B], unfinished[B], kv_len[B]) numpy int32."""

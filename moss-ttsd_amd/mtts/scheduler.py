@@ -31,14 +31,16 @@ class ContinuousBatcher:
         self.evictions = 0
         engine.sched_open(self.slots, self.gen_cap, layers=layers, do_samples=do_samples)
 
-    def run(self, prompts, max_new_tokens, seeds=None, base_seed=0):
+    def run(self, prompts, max_new_tokens, seeds=None, base_seed=0, row_ids=None):
         """prompts: list of int64 [T_i,8] delay-shifted prompts (no padding); max_new_tokens: int or list
         (HF semantics: max_length = T_i + max_new).  seeds: one Philox key per dialogue (default base_seed + i, so
         that concurrent dialogues draw from different streams).  Returns a list of int64 [T_i-7+G_i, 8] in
-        submission order."""
+        submission order.  row_ids: Philox row id per dialogue (default 0): with one shared seed and row_ids = the
+        dialogues' positions in a batch they draw what that static batch's rows draw."""
         n = len(prompts)
         mnt = [max_new_tokens] * n if np.isscalar(max_new_tokens) else list(max_new_tokens)
         seeds = list(seeds) if seeds is not None else [int(base_seed) + i for i in range(n)]
+        row_ids = [0] * n if row_ids is None else [int(r) for r in row_ids]
         results = [None] * n
         owner = [-1] * self.slots
         queue = list(range(n))
@@ -57,7 +59,7 @@ class ContinuousBatcher:
                     if live and self.eng.kv_pool_state()[1] < (ids.shape[0] - 7 + 64) // 64 + live + 1:
                         break                                         # not enough headroom next to the residents
                     try:
-                        self.eng.submit(s, ids, ids.shape[0] + int(mnt[i]), seed=int(seeds[i]))
+                        self.eng.submit(s, ids, ids.shape[0] + int(mnt[i]), seed=int(seeds[i]), row_id=row_ids[i])
                     except capi.MttsError as err:
                         if err.code != capi.ENOMEM:
                             raise

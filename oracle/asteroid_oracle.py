@@ -274,7 +274,9 @@ class AsteroidOracle:
         recorded, then the forced row is appended instead (teacher-forced replay);
         returns (ids, decisions[steps,B,8]).  forced_as_draw (replay of a SAMPLED reference run): the forced row
         replaces the step's raw draw BEFORE the state machine (which then follows the reference's history, not this
-        run's own draws); the recorded decisions are the raw draws."""
+        run's own draws); the recorded decisions are the raw draws.  forced_as_draw="all": the forced row is also the
+        raw pick of rows that are already finished (the reference keeps evaluating every row, :140-141) -- lets a test
+        script chained finished-row resurrections."""
         cfg = self.cfg
         C = cfg["channels"]
         eos, pad = cfg["eos_token_id"], cfg["speech_pad_token"]
@@ -336,7 +338,11 @@ class AsteroidOracle:
             self.last_margins.append(mg)
             if forced is not None and forced_as_draw:
                 decisions.append(nxt.copy())
-                nxt = forced[:, ids.shape[1]].copy()
+                # the draws of rows the reference has already finished are not in its output (padding is): those rows
+                # keep their own picks, unless the test scripts them too (forced_as_draw == "all")
+                fr = forced[:, ids.shape[1]]
+                take = np.ones(B, dtype=bool) if forced_as_draw == "all" else (unfinished == 1)
+                nxt = np.where(take[:, None], fr, nxt)
             is_speech = (nxt[:, 0] >= lo) & (nxt[:, 0] < hi)
             nas[(~is_speech) & (nas < 0)] = C - 1
             if cur + 1 <= tf_inputs.shape[1]:

@@ -323,6 +323,7 @@ if __name__ == "__main__":
     if "all" in which or "proc" in which:
         processors_case()
     lo = dict(emb_row_sigma=0.6, speech_boost=3.2, eos_boost=3.2)
+    WIDE = dict(hidden_size=2048, intermediate_size=6144, num_attention_heads=16, num_key_value_heads=8)
     hi = dict(emb_row_sigma=0.6, speech_boost=4.0, eos_boost=11.0)
     # name -> (cfg overrides, weight kwargs, seed, batch, prompt_len, audio_frac, max_new, extra kwargs)
     AR_CASES = {
@@ -343,6 +344,10 @@ if __name__ == "__main__":
         "ar_flush_past_max": ({}, lo, 103, 3, 24, 0.0, 20, {}),
         # processors on the greedy path (repetition penalty changes the argmax)
         "ar_rep_penalty": ({}, hi, 404, 2, 24, 0.3, 24, dict(layers=[dict(repetition_penalty=1.3)] * 8)),
+        # PRODUCTION WIDTH (round 3): the ASSUMED 1.7B layer shape -- H 2048, I 6144, 16 query / 8 KV heads x 128, the
+        # full 152 697-row channel-0 table -- at 2 layers; ragged B=3, prompts of ~64 slots (text + audio tail), 24 steps
+        "ar_wide": (WIDE, lo, 601, 3, 64, 0.3, 24, {}),
+        "ar_wide_fp32": (WIDE, lo, 601, 3, 64, 0.3, 24, dict(dtype=torch.float32)),
     }
     if "all" in which or "ar" in which:
         for name, (co, wkw, seed, b, pl, af, mn, kw) in AR_CASES.items():
@@ -353,8 +358,13 @@ if __name__ == "__main__":
         # The reference's OWN CustomMixin._sample (under RefModelSample's 4.53.2 helper shims) against the restated
         # loop above and against the committed fixtures: the state machine (EOS flush, teacher forcing, finished-row
         # padding, stopping rule) is then pinned by the reference's code, not by a restatement of it.
+        pin_path = os.path.join(HERE, "sample_pin.json")
         rec = {"transformers_version": __import__("transformers").__version__, "cases": {}}
+        if any(w.startswith("ar_") for w in which) and os.path.exists(pin_path):
+            rec["cases"] = json.load(open(pin_path))["cases"]
         for name, (co, wkw, seed, b, pl, af, mn, kw) in AR_CASES.items():
+            if any(w.startswith("ar_") for w in which) and name not in which:
+                continue                                   # `make_golden.py pin ar_wide`: only the named cases
             dtype = kw.get("dtype", torch.bfloat16)
             cfg = synth.tiny(**co)
             w = synth.synth_weights(cfg, seed, bf16=(dtype == torch.bfloat16), **wkw)
@@ -370,7 +380,7 @@ if __name__ == "__main__":
             rec["cases"][name] = {"real_sample_equals_restated_loop": ok_r, "real_sample_equals_fixture": ok_f,
                                   "out_shape": list(real.shape)}
             print(f"pin {name}: real _sample == restated loop == fixture, out {real.shape}")
-        with open(os.path.join(HERE, "sample_pin.json"), "w") as f:
+        with open(pin_path, "w") as f:
             json.dump(rec, f, indent=1)
     if "all" in which or "sampled" in which:
         sampled_case()

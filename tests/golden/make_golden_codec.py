@@ -59,18 +59,51 @@ def build_reference(cfg, w, encoder=False):
     return m
 
 
-def make_encode(name, cfg, seed, lengths):
-    """Reference XY_Tokenizer.encode (model.py:131-192) on synthetic audio -> code ids."""
+def make_encode(name, cfg, seed, lengths, margins=False):
+    """Reference XY_Tokenizer.encode (model.py:131-192) on synthetic audio -> code ids.
+    margins=True also records, per code, how safe the reference's argmin was: forward hooks on the 8 VectorQuantize
+    stages (observers only) recompute `dist` exactly as nn/quantizer.py:167-170 does from the stage's input and keep
+    `second smallest - smallest` and the smallest itself; the per-window values are stitched like the codes are
+    (model.py:170-184)."""
     w = synth_codec.synth_weights(cfg, seed, encoder=True)
     m = build_reference(cfg, w, encoder=True)
     wavs = synth_codec.synth_wavs(seed + 1, lengths)
+    calls = []                                   # one entry per inference_tokenize call: list of nq x (gap, best) [B,T']
+    hooks = []
+    if margins:
+        def hook(mod, args, out):
+            z = args[0].float()
+            enc = mod.in_project(z).float().permute(0, 2, 1).reshape(-1, mod.codebook.shape[1])
+            cb = mod.codebook.float()
+            dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
+            two = torch.topk(dist, 2, dim=1, largest=False).values
+            assert torch.equal((-dist).max(1)[1].reshape(z.shape[0], -1), out[3])       # the observer sees what the stage saw
+            calls[-1].append(((two[:, 1] - two[:, 0]).reshape(z.shape[0], -1).numpy(), two[:, 0].reshape(z.shape[0], -1).numpy()))
+        for q in m.quantizer.quantizers:
+            hooks.append(q.register_forward_hook(hook))
+        tok = m.inference_tokenize
+
+        def tok_logged(x, ln):
+            calls.append([])
+            return tok(x, ln)
+        m.inference_tokenize = tok_logged
     with torch.no_grad():
         res = m.encode([torch.from_numpy(x) for x in wavs], overlap_seconds=10, device=torch.device("cpu"))
-        # second-best distance margins of the first window (how safe each argmin is)
+    for h in hooks:
+        h.remove()
     d = dict(cfg=json.dumps(cfg), seed=seed, lengths=np.array(lengths))
     for i, cds in enumerate(res["codes_list"]):
         d[f"codes{i}"] = cds.numpy().astype(np.int16)
         print(name, i, tuple(cds.shape), cds[:, :6].tolist()[0])
+        if margins:
+            keep = 20 * cfg["input_sample_rate"] // cfg["encoder_downsample_rate"]      # 250 codes kept per window
+            gap = np.concatenate([np.stack([c[q][0][i, :keep] for q in range(cfg["nq"])]) for c in calls], axis=1)
+            best = np.concatenate([np.stack([c[q][1][i, :keep] for q in range(cfg["nq"])]) for c in calls], axis=1)
+            d[f"gap{i}"] = gap[:, :cds.shape[1]].astype(np.float32)
+            d[f"best{i}"] = best[:, :cds.shape[1]].astype(np.float32)
+            rel = d[f"gap{i}"] / np.abs(d[f"best{i}"])
+            print(name, i, "argmin gap: min abs %.3g, min rel %.3g, share rel < 1e-4: %.4f"
+                  % (d[f"gap{i}"].min(), rel.min(), (rel < 1e-4).mean()))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
 
 
@@ -94,6 +127,17 @@ def make(name, cfg, seed, lengths):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     red = synth_codec.reduced()
+    full = synth_codec.codec_config()
+    if "full" in sys.argv[1:]:
+        # PRODUCTION DEPTH (round 3): 4 + 12 transformer layers, 30 ConvNeXt blocks, whole windows
+        make("codec_full_T375", full, 21, [375])                          # exactly one full 30 s window (1 500 keys)
+        make("codec_full_T520", full, 22, [520])                          # 3 windows (starts 0, 250, 500), ragged tail
+        sys.exit(0)
+    if "encfull" in sys.argv[1:]:
+        # the two 12-layer encoders + 4-layer adapters: exact ids and the margin of every argmin
+        make_encode("codec_enc_full_12s", full, 31, [192000], margins=True)
+        make_encode("codec_enc_full_ragged", full, 32, [100000, 41000], margins=True)
+        sys.exit(0)
     if "enc" in sys.argv[1:]:
         make_encode("codec_enc_3s", red, 11, [48000])
         make_encode("codec_enc_ragged", red, 12, [80000, 33000])

@@ -13,8 +13,10 @@ torch = pytest.importorskip("torch")
 from mtts import capi, synth  # noqa: E402
 from oracle import asteroid_oracle as ao  # noqa: E402
 
-CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty", "ar_flush_past_max"]
-MARGIN_OK = 0.02
+CASES = ["ar_text_ragged", "ar_flush0", "ar_audio_tail", "ar_gqa4", "ar_rep_penalty", "ar_flush_past_max", "ar_wide"]
+# relative top-2 gap from which a decision must be identical: 2 bf16 ulps (one ulp is 2^-8..2^-7 of the value).  Below it
+# the count of agreeing decisions is pinned instead (test_parity_scale_gpu.py::test_parity_decision_counts).
+MARGIN_OK = 0.008
 
 
 def _bf16_t(a):

@@ -1,0 +1,224 @@
+"""Parity pinned at production scale and over EVERY decision.  -m gpu.
+
+* `test_parity_decision_counts`: all free decisions of the reference's greedy runs (tests/golden/ar_*.npz, written by the
+  reference's own `_sample`), no margin gate: the number on which the HIP engine equals the reference is pinned, and
+  every miss must sit on a reference margin of at most one bf16 ulp.
+* `ar_wide` / `ar_wide_fp32`: the ASSUMED 1.7B layer shape (H 2048, I 6144, 16/8 heads x 128, the full 152 697-row
+  channel-0 table), 2 layers, run by the reference (`tests/golden/make_golden.py ar ar_wide ar_wide_fp32`).
+* `codec_full_T375` / `codec_full_T520`: the codec decoder at full depth (4 + 12 transformer layers, 30 ConvNeXt
+  blocks) over whole 375-code windows; `codec_enc_full_*`: the two 12-layer encoders, exact ids.
+Measured numbers are written to gpurun_out/r03_*.json (copied to profiles/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from mtts import synth, synth_codec  # noqa: E402
+from oracle import asteroid_oracle as ao  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+BF16_ULP_REL = 2.0 ** -7          # one bf16 ulp relative to the value is in (2^-8, 2^-7]
+
+# decisions / allowed misses per fixture: profiles/r02_parity_stats.json (2 526 of 2 528) + the round-3 wide case
+PINNED = {
+    "ar_text_ragged": (897, 0), "ar_flush0": (3, 0), "ar_audio_tail": (568, 1), "ar_gqa4": (220, 1),
+    "ar_rep_penalty": (221, 0), "ar_flush_past_max": (619, 0),
+}
+
+
+def _dump(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(obj, f, indent=1)
+
+
+def _replay(name, golden_dir):
+    from mtts.engine import Engine
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth.synth_weights(cfg, int(z["seed"]), **json.loads(str(z["wkw"])))
+    eng = Engine(cfg, max_batch=4, max_seq_len=256)
+    eng.bind_state_dict(w)
+    gold = z["out_ids"]
+    T = z["input_ids"].shape[1]
+    layers = json.loads(str(z["layers"])) or None
+    out, dec = eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), layers=layers, forced=gold)
+    eng.close()
+    assert np.array_equal(out, gold)
+    return z, dec, gold[:, T - 7:].transpose(1, 0, 2)
+
+
+def test_parity_decision_counts(golden_dir):
+    """Every free decision of the six reference runs (+ the wide one): HIP == reference on at least the pinned count
+    (2 526 of 2 528 on the six, both misses one-ulp ties analysed in DESIGN §6), and any miss at all must have a
+    reference margin <= 1 bf16 ulp -- a change that flips a decision with a real margin fails here."""
+    stats = {}
+    total = hits = 0
+    for name in list(PINNED) + ["ar_wide"]:
+        z, dec, want = _replay(name, golden_dir)
+        m = z["margins"]
+        used = m < 9.0
+        n = int(used.sum())
+        ok = int((dec[used] == want[used]).sum())
+        miss = np.argwhere(used & (dec != want))
+        stats[name] = {"decisions": n, "hip_equals_reference": ok,
+                       "low_margin_decisions(<0.008)": int((used & (m < 0.008)).sum()),
+                       "exact_ties_in_reference": int((used & (m == 0)).sum()),
+                       "misses": [{"step": int(s), "row": int(b), "channel": int(c), "reference_margin": float(m[s, b, c]),
+                                   "reference_token": int(want[s, b, c]), "hip_token": int(dec[s, b, c])} for s, b, c in miss]}
+        for s, b, c in miss:
+            assert m[s, b, c] <= BF16_ULP_REL, (name, int(s), int(b), int(c), float(m[s, b, c]))
+        if name in PINNED:
+            assert n == PINNED[name][0], (name, n)
+            assert n - ok <= PINNED[name][1], (name, n, ok, stats[name]["misses"])
+            total += n
+            hits += ok
+    stats["six_fixture_total"] = {"decisions": total, "hip_equals_reference": hits}
+    _dump("r03_parity_stats.json", stats)
+    assert total == 2528 and hits >= total - 2, (total, hits)
+    w = stats["ar_wide"]
+    assert w["decisions"] == 441 and w["decisions"] - w["hip_equals_reference"] <= 2, w
+
+
+def _bits_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_wide_logits_vs_reference_fixture(golden_dir):
+    """ar_wide: the engine's bf16 logits after the prefill and after each of the first forced steps against the
+    REFERENCE's stored logits (all 7 x 1025 speech logits and the channel-0 slice 151 600..152 696 of every row):
+    within 4 bf16 ulps of the row maximum everywhere, a large share bit-identical."""
+    from mtts.engine import Engine
+    z = np.load(os.path.join(golden_dir, "ar_wide.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth.synth_weights(cfg, int(z["seed"]), **json.loads(str(z["wkw"])))
+    eng = Engine(cfg, max_batch=4, max_seq_len=256)
+    eng.bind_state_dict(w)
+    gold = z["out_ids"]
+    T = z["input_ids"].shape[1]
+    lo = int(z["ch0_lo"])
+    exact = total = 0
+    worst = 0.0
+    for s in range(12):
+        if s == 0:
+            eng.begin(z["input_ids"], z["attention_mask"], int(z["max_length"]))
+        else:
+            eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), forced=gold[:, :T - 7 + s])
+        l0, l17 = eng.read_logits()
+        ref = [_bits_to_f32(z[f"logits0_step{s}"])] + list(_bits_to_f32(z[f"logits17_step{s}"]))
+        # the reference keeps running finished rows on padding; the engine skips them (their logits are never used):
+        # a row is live at step s when the row it appends there is not the finished-row padding (eos, 1024 x 7)
+        row = gold[:, T - 7 + s]
+        live = ~((row[:, 0] == cfg["eos_token_id"]) & (row[:, 1:] == 1024).all(axis=1))
+        assert live.any()
+        for c in range(8):
+            got = l0[:, lo:] if c == 0 else l17[c - 1]
+            fin = np.isfinite(ref[c]) & live[:, None]      # the reference's log carries the -inf masks
+            r = np.where(fin, ref[c], 0)
+            scale = np.abs(r).max(axis=-1, keepdims=True)
+            err = np.abs(np.where(fin, got - r, 0)) / scale
+            worst = max(worst, float(err.max()))
+            assert (err <= 2.0 ** -6).all(), (s, c, float(err.max()))
+            exact += int((got[fin] == ref[c][fin]).sum())
+            total += int(fin.sum())
+    eng.close()
+    _dump("r03_wide_logits.json", {"steps": 12, "logits_compared": total, "bit_identical": exact,
+                                   "worst_error_over_row_max": worst})
+    assert exact >= 0.3 * total, (exact, total)
+
+
+def test_wide_fp32_strict_parity(golden_dir):
+    """ar_wide_fp32: the fp32 engine against the reference's fp32 run at the production layer shape -- strict, no
+    margin gate: every decision of the forced replay and the free run token for token."""
+    from mtts.engine import Engine
+    z = np.load(os.path.join(golden_dir, "ar_wide_fp32.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    w = synth.synth_weights(cfg, int(z["seed"]), bf16=False, **json.loads(str(z["wkw"])))
+    gold = z["out_ids"]
+    T = z["input_ids"].shape[1]
+    eng = Engine(cfg, max_batch=4, max_seq_len=256, dtype="fp32")
+    eng.bind_state_dict(w)
+    out, dec = eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]), forced=gold)
+    assert np.array_equal(out, gold)
+    want = gold[:, T - 7:].transpose(1, 0, 2)
+    used = z["margins"] < 9.0
+    miss = np.argwhere(dec != want)
+    assert len(miss) == 0, [(int(s), int(b), int(c), float(z["margins"][s, b, c])) for s, b, c in miss[:8]]
+    free = eng.generate(z["input_ids"], z["attention_mask"], int(z["max_length"]))
+    eng.close()
+    assert free.shape == gold.shape and np.array_equal(free, gold)
+    _dump("r03_wide_fp32.json", {"decisions": int(used.sum()), "identical": int((dec[used] == want[used]).sum()),
+                                 "free_run_identical": True, "min_margin": float(z["margins"][used].min())})
+
+
+# ---- codec at full depth -------------------------------------------------------------------------------------------
+def _codec_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    return z, cfg
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("name", ["codec_full_T375", "codec_full_T520"])
+def test_codec_full_depth_full_window_vs_reference(golden_dir, monkeypatch, name, mode):
+    """The product shape of the decoder -- 4 adapter + 12 decoder layers, 30 ConvNeXt blocks, attention over 1 500
+    keys -- on one exact 375-code window and on 520 codes (3 windows, ragged tail) against the reference's
+    XY_Tokenizer.decode (XY_Tokenizer/xy_tokenizer/model.py:195-256): waveform RMS error <= 1e-4 (north-star
+    tolerance) in both GEMM modes."""
+    from mtts.codec import CodecEngine
+    monkeypatch.setenv("MTTS_CODEC_GEMM", mode)
+    z, cfg = _codec_case(golden_dir, name)
+    w = synth_codec.synth_weights(cfg, int(z["seed"]))
+    codes = synth_codec.synth_codes(cfg, int(z["seed"]) + 1, list(z["lengths"]))
+    eng = CodecEngine(cfg)
+    eng.bind_state_dict(w)
+    wavs = [x.cpu().numpy() for x in eng.decode([torch.from_numpy(c) for c in codes])]
+    eng.close()
+    stride = int(z["stride"])
+    rec = {}
+    for i, wv in enumerate(wavs):
+        assert wv.shape[0] == int(z[f"wav{i}_len"])
+        ref = z[f"wav{i}_sub"].astype(np.float64)
+        err = float(np.sqrt(np.mean((wv[::stride].astype(np.float64) - ref) ** 2)))
+        sig = float(np.sqrt(np.mean(ref ** 2)))
+        rec[f"wav{i}"] = {"rms_error": err, "signal_rms": sig, "samples": int(wv.shape[0])}
+        assert sig > 1e-3
+        assert err <= 1e-4, (name, mode, err, sig)
+    _dump(f"r03_codec_full_{name}_{mode}.json", rec)
+
+
+@pytest.mark.parametrize("name", ["codec_enc_full_12s", "codec_enc_full_ragged"])
+def test_encoder_full_depth_exact_ids(golden_dir, name):
+    """The two 12-layer OmniAudioEncoders + the 4-layer adapters + down-conv + 8-stage RVQ search against the
+    reference's XY_Tokenizer.encode (model.py:131-192): exact code ids.  The fixture carries the reference's own
+    argmin gap of every code; a miss is reported with it (and fails)."""
+    from mtts.codec import CodecEngine
+    z, cfg = _codec_case(golden_dir, name)
+    w = synth_codec.synth_weights(cfg, int(z["seed"]), encoder=True)
+    wavs = synth_codec.synth_wavs(int(z["seed"]) + 1, list(z["lengths"]))
+    eng = CodecEngine(cfg)
+    eng.bind_state_dict(w)
+    got = eng.encode([torch.from_numpy(x) for x in wavs])
+    eng.close()
+    rec = {"items": []}
+    bad = []
+    for i, g in enumerate(got):
+        want = z[f"codes{i}"].astype(np.int64)
+        g = g.cpu().numpy()
+        assert g.shape == want.shape, (g.shape, want.shape)
+        gap, best = z[f"gap{i}"], z[f"best{i}"]
+        rel = gap / np.abs(best)
+        miss = np.argwhere(g != want)
+        rec["items"].append({"codes": int(want.size), "identical": int((g == want).sum()),
+                             "min_abs_gap": float(gap.min()), "min_rel_gap": float(rel.min()),
+                             "misses": [{"stage": int(q), "frame": int(t), "abs_gap": float(gap[q, t]), "rel_gap": float(rel[q, t])}
+                                        for q, t in miss[:32]]})
+        bad += [(i, int(q), int(t), float(gap[q, t]), float(rel[q, t])) for q, t in miss]
+    _dump(f"r03_{name}.json", rec)
+    assert not bad, bad[:16]
