@@ -10,7 +10,9 @@ A "step" = one decode step of the whole batch = B frames = 8*B codec ids.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), dialogues are
 independent, so the batch is sharded (32 per rank, weak scaling); the only
-collectives are the weight broadcast at start-up and the metric reduction.
+collectives are the weight broadcast at start-up (flat buckets), the metric reduction,
+and -- outside the timed region, reported as `end_to_end` -- the gather of every rank's
+decoded audio on rank 0 (BASELINE configs[3]).
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,17 +42,19 @@ def algorithmic_bytes_per_step(cfg, B, L):
 
 
 def make_weights_on_device(cfg, seed, device, rank, world):
-    """Random-init weights of the architecture, generated on rank 0's GPU and broadcast
-    over RCCL -- yields (name, tensor) one at a time to bound memory."""
+    """Random-init weights of the architecture, generated on rank 0's GPU; at N>1 they reach the other ranks the way a
+    checkpoint does in inference_sharded.load_model_sharded: mtts.dist.broadcast_state_dict, a few flat <= 1 GiB
+    buckets over RCCL.  Yields (name, tensor)."""
     import torch
-    import torch.distributed as dist
+    from mtts import dist as mdist
     from mtts import synth
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     lo, hi = cfg["speech_token_range"]
-    for name, shape, kind in synth.weight_shapes(cfg):
-        t = torch.empty(shape, dtype=torch.bfloat16, device=device)
-        if rank == 0:
+
+    def gen():
+        for name, shape, kind in synth.weight_shapes(cfg):
+            t = torch.empty(shape, dtype=torch.bfloat16, device=device)
             if kind == "norm":
                 t.copy_(1.0 + 0.1 * torch.randn(shape, device=device, generator=g))
             else:
@@ -58,9 +62,12 @@ def make_weights_on_device(cfg, seed, device, rank, world):
                 if name.endswith("embedding_list.0.weight"):
                     # keep channel 0 inside the speech range so no dialogue flushes early
                     t[lo:hi] *= 8.0
-        if world > 1:
-            dist.broadcast(t, src=0)
-        yield name, t
+            yield name, t
+
+    if world == 1:
+        yield from gen()                         # one tensor at a time: nothing to hold on to
+    else:
+        yield from mdist.broadcast_state_dict(dict(gen()) if rank == 0 else {}, device)
 
 
 def cpu_baseline(cfg, B, L, layers_sampled=1, steps=2, seed=3):
@@ -127,7 +134,7 @@ def host_cores():
     return n
 
 
-def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=32):
+def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, windows_per_call=32, keep=None):
     """End-to-end figure: prefill + every decode step run so far + codec decode of ALL the
     frames this run generated (full-depth XY_Tokenizer decoder, 30 s windows / 20 s stride as the reference)."""
     import torch
@@ -150,6 +157,8 @@ def end_to_end_leg(eng, device, B, T_prompt, t_prefill, t_decode, steps_done, wi
     for b0 in range(0, B, windows_per_call):
         wavs = cod.decode([t[:, b] for b in range(b0, min(B, b0 + windows_per_call))])
         total += sum(int(w.shape[0]) for w in wavs)
+        if keep is not None:
+            keep.extend(wavs)
     torch.cuda.synchronize()
     t_codec = time.perf_counter() - t0
     cod.close()
@@ -403,6 +412,38 @@ def main():
     dt_max = float(tmax.item())
     total_ids = float(units.item())
 
+    # N>1 (BASELINE configs[3]: "RCCL broadcast weights, gather audio"): every rank decodes the frames it generated and
+    # rank 0 receives all the audio (mtts.dist.gather_audio: one exact-size buffer per rank over its own xGMI link)
+    e2e_sharded = None
+    if world > 1 and not args.no_codec and not args.fake_context:
+        from mtts import dist as mdist
+        wavs = []
+        leg = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all, keep=wavs)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # (gloo rehearsals on a 1-GPU box exchange through host memory: gloo has no device send / recv)
+        got = mdist.gather_audio([(rank * B + i, w) for i, w in enumerate(wavs)], device if backend == "nccl" else torch.device("cpu"))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_gather = time.perf_counter() - t0
+        tm = torch.tensor([leg["prefill_s"], leg["decode_s"], leg["codec_s"], t_gather], dtype=torch.float64, device=device)
+        sm = torch.tensor([leg["audio_seconds"], float(leg["frames"])], dtype=torch.float64, device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            assert len(got) == world * B and all(w is not None for _, w in got)
+            gathered = sum(int(w.numel()) for _, w in got)
+            assert abs(gathered / 24000.0 - float(sm[0])) < 1e-3 * float(sm[0])
+            wall = float(tm.sum())
+            e2e_sharded = {"prefill_s": float(tm[0]), "decode_s": float(tm[1]), "codec_s": float(tm[2]), "gather_s": float(tm[3]),
+                           "gathered_bytes": gathered * 4, "gather_GBps_into_rank0": gathered * 4 / max(float(tm[3]), 1e-9) / 1e9,
+                           "frames": int(sm[1]), "audio_seconds": float(sm[0]), "codec_ids_per_s": float(sm[1]) * 8 / wall,
+                           "real_time_factor": float(sm[0]) / wall,
+                           "note": "slowest rank's prefill + decode (context ramp + timed steps) + codec decode of all its frames, "
+                                   "then the audio of every rank gathered on rank 0"}
+        del wavs, got
+
     if rank == 0:
         Lt = L - args.profile_steps - K // 2          # mean KV length inside the timed region
         step_bytes, Wb, kvb = algorithmic_bytes_per_step(cfg, B, Lt)
@@ -461,6 +502,8 @@ def main():
             out["invalid"] = "depth overridden with --layers"
         if args.fake_context:
             out["invalid"] = "context faked with mtts_debug_set_kv_len (profiling run)"
+        if e2e_sharded is not None:
+            out["end_to_end"] = e2e_sharded
         if world == 1 and not args.no_codec:
             if not args.fake_context:
                 out["end_to_end"] = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all)
@@ -476,9 +519,28 @@ def main():
             cores = host_cores()
             st_time, per_layer, heads_t = cpu_baseline(cfg, B, L)
             out["cpu_baseline"] = {"value": B * 8 / st_time, "unit": "codec_tokens/s", "cores": cores, "kind": "port",
-                                   "sample": f"numpy oracle, 1 of {cfg['num_hidden_layers']} layers at full width + 8 heads, "
+                                   "sample": f"numpy oracle (a port, slower than the reference's torch CPU path), EXTRAPOLATED: 1 of "
+                                             f"{cfg['num_hidden_layers']} layers at full width + 8 heads, "
                                              f"batch {B} at KV length {L}, best of 2 decode steps; per-layer time "
                                              f"({per_layer:.3f} s) scaled to full depth, heads {heads_t:.3f} s"}
+            # the REAL reference (AsteroidTTSInstruct.forward, eager and SDPA) timed in the build container by
+            # tools/cpu_reference_timing.py -- it cannot travel to this box; quoted beside the port's figure
+            try:
+                rc = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_reference.json")))
+                if B == rc["batch"] and L == rc["kv_len"]:
+                    out["cpu_baseline"]["reference_container"] = {
+                        "kind": "reference", "cores": rc["cores"], "torch": rc["torch"], "unit": "codec_tokens/s",
+                        "eager": rc["eager"]["codec_ids_per_s"], "sdpa": rc["sdpa"]["codec_ids_per_s"],
+                        "s_per_step_eager": rc["eager"]["s_per_step_28_layers"], "s_per_step_sdpa": rc["sdpa"]["s_per_step_28_layers"],
+                        "sample": "reference forward, bf16, one decode step at B=32 / KV 4096 with 2 and 4 layers at the ASSUMED width "
+                                  "-> fixed + 28 x per-layer; measured in the build container, not on this box",
+                        "source": "profiles/r03_cpu_reference.json"}
+                    if "codec_decode" in out:
+                        out["codec_decode"].setdefault("cpu_baseline", {})["reference_container"] = {
+                            "kind": "reference", "cores": rc["cores"], "value": rc["codec_decode"]["audio_s_per_s"],
+                            "unit": "audio_seconds/s", "sample": "XY_Tokenizer.decode, full depth, one 375-code window"}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -526,13 +526,14 @@ __global__ void update_kernel(const int32_t* __restrict__ decisions, int32_t* __
             const size_t slot = ((size_t)b * cap + step) * 8;
             const bool as_draw = forced && ls->forced_draw;
             if (as_draw) {          // the log keeps the raw draws; the reference's history drives the state machine
+                // (mode 2, tests of chained resurrections: the forced row is also the raw draw of a cut-off row that
+                //  the reference keeps evaluating -- a real reference run does not record those draws)
+                const bool take = s.unfinished != 0 || (linger && ls->forced_draw == 2);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     dec_log[slot + c] = tok[c];
                     const int f = forced[slot + c];
-                    // (mode 2, tests of chained resurrections: the forced row is also the raw draw of a cut-off row that
-                    //  the reference keeps evaluating -- a real reference run does not record those draws)
-                    if (f >= 0 && (s.unfinished || (linger && ls->forced_draw == 2))) tok[c] = f;
+                    if (f >= 0 && take) tok[c] = f;
                 }
             }
             // :140-141

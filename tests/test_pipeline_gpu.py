@@ -21,24 +21,7 @@ class Tok:
         return [min(ord(c), 151000) for c in s]
 
 
-def _gp(cfg):
-    """generator_params dict (yaml shape) for a reduced-depth codec."""
-    enc = {"encoder_layers": cfg["enc_layers"], "d_model": 768, "encoder_attention_heads": 12, "encoder_ffn_dim": 3072,
-           "max_audio_seconds": 30, "sampling_rate": 16000, "hop_length": 160, "stride_size": 2}
-    return {"input_sample_rate": 16000, "output_sample_rate": 24000,
-            "feature_extractor_kwargs": {"n_fft": 400, "hop_length": 160, "nb_max_frames": 3000},
-            "semantic_encoder_kwargs": enc, "acoustic_encoder_kwargs": enc,
-            "semantic_encoder_adapter_kwargs": {"encoder_layers": cfg["sem_adapter_layers"]},
-            "pre_rvq_adapter_kwargs": {"encoder_layers": cfg["pre_rvq_layers"]},
-            "downsample_kwargs": {"avg_pooler": 4},
-            "quantizer_kwargs": {"num_quantizers": 8, "codebook_size": 1024, "rvq_dim": 512, "output_dim": 3072},
-            "post_rvq_adapter_kwargs": {"encoder_layers": cfg["adapter_layers"], "d_model": 768,
-                                        "encoder_attention_heads": 12, "encoder_ffn_dim": 3072, "max_source_positions": 375},
-            "upsample_kwargs": {"stride": 4},
-            "acoustic_decoder_kwargs": {"decoder_layers": cfg["dec_layers"], "d_model": 768, "decoder_attention_heads": 12,
-                                        "decoder_ffn_dim": 3072, "max_audio_seconds": 30, "sampling_rate": 16000,
-                                        "hop_length": 160, "stride_size": 2, "num_mel_bins": 80},
-            "vocos_kwargs": {"dim": 512, "intermediate_dim": 4096, "num_layers": cfg["voc_layers"], "n_fft": 960, "hop_size": 240}}
+from test_pipeline_gpu_helpers import generator_params as _gp  # noqa: E402
 
 
 def test_process_batch_text_only_end_to_end():
@@ -192,3 +175,179 @@ def test_from_pretrained_directory_and_large_batch(tmp_path):
         assert (o[short, n:, 0] == cfg["eos_token_id"]).all() and (o[short, n:, 1:] == 1024).all()
     with pytest.raises(NotImplementedError):
         AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.float16)
+
+
+def test_config5_voice_clone_long_context_end_to_end():
+    """BASELINE configs[4] in one piece at reduced width: two dialogues, each with 5 s of prompt audio ->
+    spt.encode (HIP encoder) -> prompt layout + delay pattern -> ragged prefill of ~8.2 k / ~7 k tokens -> 90 decode
+    steps at an 8.3 k-token context -> un-shift -> decode_each (HIP codec).  Checked against the oracles end to end:
+    the prompt codes (encoder oracle, exact), every generated token (the engine's run teacher-forced through the AR
+    oracle: the oracle's own decision must be the engine's token wherever its top-2 margin is not a bf16 tie), and
+    both waveforms (codec oracle, RMS <= 1e-4)."""
+    import generation_utils as gu
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    cfg = synth.tiny(max_position_embeddings=16384)
+    w = synth.synth_weights(cfg, 301, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    new = 90
+    model = AsteroidTTSInstruct.from_state_dict(cfg, w, GenerationConfig(max_new_tokens=new, eos_token_id=cfg["eos_token_id"]))
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1, enc_layers=1)
+    cw = synth_codec.synth_weights(ccfg, 12, encoder=True)
+    spt = XY_Tokenizer(_gp(ccfg), cw).eval().to("cuda")
+    model = model.eval().to("cuda")
+    wavs = [torch.from_numpy(x)[None] for x in synth_codec.synth_wavs(5, [16000 * 5, 16000 * 5 - 700])]
+    rng = np.random.default_rng(4)
+    long_text = ["[S1]" + "".join(chr(int(c)) for c in rng.integers(0x4e00, 0x9000, n)) for n in (8100, 6900)]
+    items = [{"text": long_text[0], "prompt_audio": (wavs[0], 16000), "prompt_text": "[S1]reference one"},
+             {"text": long_text[1], "prompt_audio": (wavs[1], 16000), "prompt_text": "[S2]reference two"}]
+    texts, results = gu.process_batch(items, Tok(), model, spt, "cuda", "sys", 0)
+    assert all(r is not None for r in results)
+    # (1) prompt codes: the engine was fed exactly what the encoder oracle produces
+    enc = co.CodecEncodeOracle({**synth_codec.codec_config(), **ccfg}, cw)
+    for wv in wavs:
+        want = enc.encode([wv[0].numpy()])[0]
+        got = spt.encode([wv[0]])["codes_list"][0].cpu().numpy()
+        assert got.shape == (8, wv.shape[1] // 1280) and np.array_equal(got, want)
+    # (2) the same prompts through the glue, the engine's tokens through the AR oracle
+    seqs = [gu.shifting_inputs(gu.process_inputs(Tok(), spt, "sys", t["final_text"], "cuda", audio_data=wv), Tok())
+            for t, wv in zip(texts, wavs)]
+    ids, mask = gu.rpadding(seqs, 8, Tok())
+    T = ids.shape[1]
+    assert T > 8200 and int(mask[1].sum()) < T - 1000           # 8.2 k context, ragged by more than a thousand tokens
+    out = model.generate(input_ids=ids.cuda(), attention_mask=mask.cuda()).cpu().numpy()
+    assert out.shape[1] >= T - 7 + new
+    orc = ao.AsteroidOracle(cfg, w, "bf16")
+    orc.prefill_chunk = 512
+    _, odec, _ = orc.generate(ids.numpy(), mask.numpy(), T + new, forced=out)
+    margins = np.stack(orc.last_margins)
+    want = out[:, T - 7:].transpose(1, 0, 2)[:odec.shape[0]]
+    free = np.ones_like(margins, dtype=bool)
+    for s in range(7):
+        free[s, :, s + 1:] = False
+    safe = free & (margins >= 0.02)          # oracle-vs-engine gate (tests/test_engine_gpu.py: MARGIN_ORACLE)
+    assert safe.sum() > 0.8 * free.sum()
+    assert np.array_equal(odec[safe], want[safe])
+    assert np.array_equal(odec[~free], want[~free])
+    assert int(model._engine.seq_state()[2].max()) >= 8300     # the decode did run at an 8.3 k context
+    # (3) waveforms: un-shift, codec oracle
+    speech = ao.unshift_outputs(out, T - 7)
+    last = ao.find_max_valid_positions(speech)
+    dec = co.CodecOracle(ccfg, cw)
+    for i, r in enumerate(results):
+        assert last[i] + 1 >= new - 7
+        ref = dec.decode([speech[i, :last[i] + 1].T])[0]
+        got = r["audio_data"][0].numpy()
+        assert got.shape == ref.shape
+        assert np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) <= 1e-4
+
+
+def test_more_than_128_rows_take_the_scheduled_path_and_equal_their_batch1_runs():
+    """AsteroidTTSInstruct.generate with 134 rows (> MAX_ENGINE_BATCH): `_generate_scheduled` serves them through the
+    continuous batcher.  Every row -- sampled on all channels -- equals its own batch-1 run with the same seed and its
+    Philox row id (so the same seed and prompts give the same tokens on either side of the 128-row limit), the rows that
+    finish early are followed by the reference's finished-row padding (eos, 1024 x 7), and the first 128 rows equal
+    ONE static batch of those rows wherever no dialogue is cut off by max_length (the reference keeps evaluating such
+    rows, the scheduler lets them leave)."""
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 311, emb_row_sigma=0.6, speech_boost=5.0, eos_boost=5.0)
+    layers = [dict(top_k=20, top_p=0.9, temperature=1.1, repetition_penalty=1.1)] * 8
+    gc = GenerationConfig(max_new_tokens=30, do_samples=[True] * 8, layers=layers, eos_token_id=cfg["eos_token_id"])
+    model = AsteroidTTSInstruct.from_state_dict(cfg, w, gc).eval().to("cuda")
+    B = 134
+    ids, mask = synth.synth_prompts(cfg, 312, B, 40, 0.3, True)
+    T = ids.shape[1]
+    out = model.generate(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), seed=77).numpy()
+    assert out.shape[0] == B and out.shape[2] == 8
+    solo = Engine(cfg, max_batch=1, max_seq_len=256)
+    solo.bind_state_dict(w)
+    eos = cfg["eos_token_id"]
+    early = 0
+    for b in range(B):
+        pad = int(np.argmax(mask[b] > 0))
+        p = ids[b, pad:]
+        alone = solo.generate(p[None], np.ones((1, p.shape[0])), p.shape[0] + 30, layers=layers, do_samples=[True] * 8,
+                              seed=77, row_ids=[b])[0]
+        gen = alone[p.shape[0] - 7:]
+        assert np.array_equal(out[b, T - 7:T - 7 + gen.shape[0]], gen), b
+        rest = out[b, T - 7 + gen.shape[0]:]
+        assert (rest[:, 0] == eos).all() and (rest[:, 1:] == 1024).all(), b
+        early += int(gen.shape[0] < out.shape[1] - (T - 7))
+    solo.close()
+    assert early >= 5                                          # some dialogues did finish early and were padded
+    # the first 128 rows as one static batch with the same seed
+    static = model.generate(input_ids=torch.from_numpy(ids[:128]), attention_mask=torch.from_numpy(mask[:128]), seed=77).numpy()
+    n = min(static.shape[1], out.shape[1])
+    same = [b for b in range(128) if np.array_equal(static[b, :n], out[b, :n])]
+    assert len(same) >= 120, len(same)
+
+
+def test_sharded_entry_point_world1_equals_process_batch():
+    """inference_sharded.process_batch_sharded without a process group (one GPU) is generation_utils.process_batch:
+    same text records, same audio bit for bit (greedy)."""
+    import generation_utils as gu
+    import inference_sharded as ish
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 103, emb_row_sigma=0.6, speech_boost=4.0, eos_boost=1.0)
+    model = AsteroidTTSInstruct.from_state_dict(cfg, w, GenerationConfig(max_new_tokens=20, eos_token_id=cfg["eos_token_id"]))
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1)
+    spt = XY_Tokenizer(_gp(ccfg), synth_codec.synth_weights(ccfg, 9)).eval().to("cuda")
+    model = model.eval().to("cuda")
+    items = [{"text": "[S1]One.[S2]Two, a little longer."}, {"text": "[S1]Three"}, {"text": "[S2]And the fourth item."}]
+    assert ish.estimate_work(items, Tok(), "sys") == [len(it["text"].replace("[S1]", "<speaker1>").replace("[S2]", "<speaker2>")) for it in items]
+    t1, a1 = gu.process_batch(items, Tok(), model, spt, "cuda", "sys", 2)
+    t2, a2 = ish.process_batch_sharded(items, Tok(), model, spt, "cuda", "sys", 2)
+    assert t1 == t2 and len(a1) == len(a2) == 3
+    for x, y in zip(a1, a2):
+        assert x["index"] == y["index"] and x["sample_rate"] == y["sample_rate"]
+        assert torch.equal(x["audio_data"], y["audio_data"])
+
+
+def test_finetune_data_path_through_the_hip_encoder(tmp_path):
+    """finetune/data_preprocess.py on the real engine: both JSONL formats, `spt.encode` = the HIP
+    encoder.  The speech rows of input_ids are the encoder oracle's codes (+151665 on channel 0), two recordings are
+    joined at token level, labels follow the reference's masks, and the files have the reference's layout."""
+    import pickle
+    import generation_utils as gu
+    from finetune import data_preprocess as dp
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1, enc_layers=1)
+    cw = synth_codec.synth_weights(ccfg, 14, encoder=True)
+    spt = XY_Tokenizer(_gp(ccfg), cw).eval()
+    wavs = synth_codec.synth_wavs(8, [16000 * 3, 16000 * 2 + 500, 16000 * 4])
+    for name, x in zip(("a.wav", "ref.wav", "main.wav"), wavs):
+        gu.save_wav(str(tmp_path / name), torch.from_numpy(x)[None], 16000)
+    items = [{"file_path": str(tmp_path / "a.wav"), "full_transcript": "[S1]Hello there![S2]Hi."},
+             {"reference_audio": str(tmp_path / "ref.wav"), "reference_text": "[S1]ref.", "audio": str(tmp_path / "main.wav"), "text": "[S2]main text."}]
+    jl = tmp_path / "d.jsonl"
+    jl.write_text("\n".join(json.dumps(it) for it in items) + "\n")
+
+    class Tok2(Tok):
+        def encode(self, s, add_special_tokens=True):
+            return [min(ord(c), 151000) for c in s]
+
+    dp.process_data(str(jl), "unused", str(tmp_path / "out"), data_name="d", use_normalize=True, tokenizer=Tok2(), spt=spt, device="cuda")
+    metas = np.load(tmp_path / "out" / "d_metas.npy")
+    assert metas.shape == (3, 2)
+    enc = co.CodecEncodeOracle({**synth_codec.codec_config(), **ccfg}, cw)
+    # what the files' audio was after the PCM16 round trip of save_wav / _read_wav
+    loaded = [gu.load_audio_data(str(tmp_path / n))[0].numpy() for n in ("a.wav", "ref.wav", "main.wav")]
+    want_codes = [enc.encode([x])[0].T for x in loaded]                      # [frames, 8]
+    want_audio = [want_codes[0], np.concatenate([want_codes[1], want_codes[2]], axis=0)]
+    with open(tmp_path / "out" / "d.pkl", "rb") as f:                         # written by this test
+        for k, off in enumerate(metas[0]):
+            f.seek(int(off))
+            e = pickle.load(f)
+            ids, labels = np.array(e["input_ids"]), np.array(e["labels"])
+            total, n_audio = int(metas[1, k]), int(metas[2, k])
+            assert ids.shape == labels.shape == (total, 8) and n_audio == want_audio[k].shape[0]
+            a0 = total - n_audio - len("<|end_of_speech|>")
+            speech = ids[a0:a0 + n_audio].copy()
+            speech[:, 0] -= 151665
+            assert np.array_equal(speech, want_audio[k]), k
+            assert np.array_equal(labels[a0:a0 + n_audio], ids[a0:a0 + n_audio]) and (labels[:a0] == -100).all()
+            assert np.array_equal(labels[a0 + n_audio:, 0], ids[a0 + n_audio:, 0])
+    assert list(metas[2]) == [37, 25 + 50]
