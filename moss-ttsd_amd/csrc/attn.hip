@@ -164,17 +164,11 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 // d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
 // FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
 // writes it to the cache and patches it into the page it has just loaded.
-// COMBINE: no attn_combine launch behind this one.  Every block publishes its chunk partial write-through (16-byte sc1
-// stores, drained), then one lane takes a ticket on the (row, kv head) counter; the block whose ticket is the last of
-// the group -- nobody ever waits -- acquires and sums the group's partials IN CHUNK ORDER (the order attn_combine_kernel
-// uses, so the bf16 output has the same bits), writes the X-fragment rows and re-arms the counter for the next launch
-// (cdna_hip_programming.md Guideline 16: sc1 payload + agent-scope ticket, acquire before the plain... here sc1 loads).
-template <int G, bool FUSED, bool COMBINE>
+template <int G, bool FUSED>
 __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
-    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f, unsigned int* __restrict__ arrive,
-    uint16_t* __restrict__ out_packed) {
+    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f) {
     __shared__ float red[PV_WAVES][G][MTTS_HD];
     __shared__ uint16_t pbuf[PV_WAVES][G][MTTS_PAGE];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[MTTS_HD];
@@ -292,66 +286,12 @@ __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
             if (sub == 0) red[wave][g][dl * 4 + i] = v;
         }
     __syncthreads();
-    if (!COMBINE) {
-        for (int i = threadIdx.x; i < G * MTTS_HD; i += PV_WAVES * 64) {
-            int g = i / MTTS_HD, d = i % MTTS_HD;
-            float v = red[0][g][d];
+    for (int i = threadIdx.x; i < G * MTTS_HD; i += PV_WAVES * 64) {
+        int g = i / MTTS_HD, d = i % MTTS_HD;
+        float v = red[0][g][d];
 #pragma unroll
-            for (int w = 1; w < PV_WAVES; ++w) v += red[w][g][d];
-            opart[(((size_t)r * nq + kvh * G + g) * nchunks_max + chunk) * MTTS_HD + d] = v;
-        }
-        return;
-    }
-    // ---- publish this chunk's partial: thread t < 32 G owns dims 4 (t % 32) .. +3 of head t / 32 -> one 16-byte sc1 store
-    const int g_ = threadIdx.x >> 5, d4 = (threadIdx.x & 31) * 4;
-    float* grp = opart + ((size_t)r * nq + kvh * G) * nchunks_max * MTTS_HD;          // this (row, kv head)'s G x chunks x 128
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(grp, 0, G * nchunks_max * MTTS_HD * 4, 0x00020000);
-    if ((int)threadIdx.x < 32 * G) {
-        f32x4_t v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a = red[0][g_][d4 + i];
-#pragma unroll
-            for (int w = 1; w < PV_WAVES; ++w) a += red[w][g_][d4 + i];
-            v[i] = a;
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, ((g_ * nchunks_max + chunk) * MTTS_HD + d4) * 4, 0, 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
-    __syncthreads();
-    const int nch = (npages + ATT_PB - 1) / ATT_PB;          // blocks of this (row, kv head) that take a ticket
-    int* lastp = (int*)&pbuf[0][0][0];                        // (LDS word reuse: the probabilities are done with)
-    if (threadIdx.x == 0) {
-        unsigned int* c = arrive + (size_t)r * nkv + kvh;
-        const unsigned int t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == (unsigned int)(nch - 1);
-        if (last) {
-            __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *lastp = last;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!*lastp) return;
-    if ((int)threadIdx.x < 32 * G) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            u32x4_t t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                t[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((g_ * nchunks_max + min(c0 + j, nch - 1)) * MTTS_HD + d4) * 4, 0, 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (c0 + j < nch) {
-                    const f32x4_t v = __builtin_bit_cast(f32x4_t, t[j]);
-                    s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
-                }
-        }
-        u32x2_t o;
-        o.x = pack2(s0, s1);
-        o.y = pack2(s2, s3);
-        *(u32x2_t*)(out_packed + xpack_off(r, (kvh * G + g_) * MTTS_HD + d4, nq * MTTS_HD)) = o;
+        for (int w = 1; w < PV_WAVES; ++w) v += red[w][g][d];
+        opart[(((size_t)r * nq + kvh * G + g) * nchunks_max + chunk) * MTTS_HD + d] = v;
     }
 }
 
@@ -584,7 +524,7 @@ template <int G>
 static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                           int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                          const QkvFuse* fuse, unsigned int* arrive, int phase, hipStream_t st) {
+                          const QkvFuse* fuse, int phase, hipStream_t st) {
     if (phase == 11) {   // prefill tiles (32 consecutive positions of one dialogue per tile)
         dim3 ga((pages_bound + 3) / 4, nkv, R / MTTS_MAXR);
         hipLaunchKernelGGL((attn_prefill_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
@@ -613,41 +553,30 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
             hipLaunchKernelGGL((attn_scores_kernel<G, false>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache,
                                page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f);
     }
-    if (phase == 4) {      // P.V with the chunk sum inside (no phase 3 behind it): needs the arrival counters
-        dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
-        if (fuse)
-            hipLaunchKernelGGL((attn_pv_kernel<G, true, true>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, arrive, (uint16_t*)out_packed);
-        else
-            hipLaunchKernelGGL((attn_pv_kernel<G, false, true>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, arrive, (uint16_t*)out_packed);
-        return;
-    }
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
         if (fuse)
-            hipLaunchKernelGGL((attn_pv_kernel<G, true, false>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, nullptr, nullptr);
+            hipLaunchKernelGGL((attn_pv_kernel<G, true>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
+                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
         else
-            hipLaunchKernelGGL((attn_pv_kernel<G, false, false>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, nullptr, nullptr);
+            hipLaunchKernelGGL((attn_pv_kernel<G, false>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
+                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
     }
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, (nq + 3) / 4), dim3(512), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
 }
 
-// phase 1/2/3 = scores / P.V / combine for decode-style rows (one dialogue per row), 4 = P.V + combine in one launch
-// (`arrive`: zeroed uint32 [R][nkv] ticket counters, re-armed by the kernel), 11/12/13 = the same for prefill
+// phase 1/2/3 = scores / P.V / combine for decode-style rows (one dialogue per row), 11/12/13 = the same for prefill
 // tiles.  `fuse` (decode rows only) moves the q/k/v epilogue into phases 1 and 2: no qkv_post launch before them.
 int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                const QkvFuse* fuse, unsigned int* arrive, int phase, hipStream_t st) {
+                const QkvFuse* fuse, int phase, hipStream_t st) {
     int G = nq / nkv;
 #define MTTS_ATT(GG)                                                                                              \
     launch_attn_g<GG>(qbuf, kcache, vcache, page_table, meta, scores, stats, opart, out_packed, R, pages_bound,   \
-                      max_pages, total_pages, nchunks_max, nq, nkv, scale, fuse, arrive, phase, st)
+                      max_pages, total_pages, nchunks_max, nq, nkv, scale, fuse, phase, st)
     if (G == 1) MTTS_ATT(1);
     else if (G == 2) MTTS_ATT(2);
     else if (G == 4) MTTS_ATT(4);

@@ -49,7 +49,7 @@ void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st);
 int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                const QkvFuse* fuse, unsigned int* arrive, int phase, hipStream_t st);
+                const QkvFuse* fuse, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
 struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, logits_f32; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
@@ -143,8 +143,6 @@ struct MttsEngine {
     void *logits0 = nullptr, *logits17 = nullptr, *join_logits0 = nullptr, *join_logits17 = nullptr;
     void* scores = nullptr;
     float *stats = nullptr, *opart = nullptr;
-    unsigned int* attn_arrive = nullptr;   // [MTTS_RCAP][nkv] ticket counters of the P.V kernel's in-launch chunk sum
-    bool pv_combine = true;             // decode rows: chunk sum inside the P.V launch (MTTS_PV_COMBINE=0: its own launch)
     // kv
     void *kcache = nullptr, *vcache = nullptr;
     size_t layer_stride = 0;           // elements per layer in each cache
@@ -384,7 +382,6 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->device = device;
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
     if (const char* g = getenv("MTTS_FUSE_QKV_MAX")) e->fuse_qkv_max = atoi(g);
-    if (const char* g = getenv("MTTS_PV_COMBINE")) e->pv_combine = atoi(g) != 0;
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     if (const char* g = getenv("MTTS_SMALL_ROWS")) e->small_rows = std::min(std::max(atoi(g), 0), SMALL_RP);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
@@ -468,7 +465,6 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     TRY(dalloc((uint16_t**)&e->scores, (size_t)MTTS_PFCAP * e->nq * e->max_pages * MTTS_PAGE));
     TRY(dalloc(&e->stats, (size_t)MTTS_PFCAP * e->nq * e->max_pages * 2));
     TRY(dalloc(&e->opart, (size_t)MTTS_PFCAP * e->nq * ((e->max_pages + ATT_PF - 1) / ATT_PF) * MTTS_HD));   // prefill chunking is the finer one
-    TRY(dalloc(&e->attn_arrive, (size_t)MTTS_RCAP * e->nkv));
     }
     // state
     TRY(dalloc(&e->d_seqs, MTTS_RCAP));
@@ -511,7 +507,7 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
     }
     void* ptrs[] = {e->partial2, e->x2, e->act_rm, e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
                     e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->join_logits0, e->join_logits17, e->scores, e->stats,
-                    e->opart, e->attn_arrive, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
+                    e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
                     e->d_cur, e->d_gen, e->d_declog, e->d_forced, e->d_tf, e->d_bitmaps, e->d_scfg, e->d_pf_tokens,
                     e->d_pf_meta};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -724,7 +720,7 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
             prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
                             pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
-                            fused ? &fz : nullptr, nullptr, phase, st))
+                            fused ? &fz : nullptr, phase, st))
                 return fail(MTTS_EINVAL, "attention group size not built");
             prof_end(e, st, ev);
         }
@@ -790,14 +786,12 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
         // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
         const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
-        // decode rows: the chunk sum rides inside the P.V launch (phase 4 instead of 2 + 3)
-        const bool pvc = heads == 1 && e->pv_combine;
-        for (int phase = 1; phase <= (pvc ? 2 : 3); ++phase) {
+        for (int phase = 1; phase <= 3; ++phase) {
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
                             pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
-                            fused ? &fz : nullptr, e->attn_arrive, (pvc && phase == 2) ? 4 : ph0 + phase, st))
+                            fused ? &fz : nullptr, ph0 + phase, st))
                 return fail(MTTS_EINVAL, "attention group size not built");
             if (phase < 3) prof_end(e, st, ev);
         }
@@ -1594,24 +1588,13 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
     HIPCHK(hipMemcpy(lens, host_lens, R * 4, hipMemcpyHostToDevice));
     launch_pack_kv_pages(dev_k, dev_v, kc, vc, pt, lens, R, Lmax, nkv, max_pages, total_pages, st);
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
-    // the launches of the product's decode step: scores, then P.V with the chunk sum inside (MTTS_PV_COMBINE=0: P.V and
-    // the combine launch behind it); run TWICE in the default form so that the self-re-armed ticket counters are exercised
-    unsigned int* arrive = nullptr;
-    TRY(dalloc(&arrive, (size_t)MTTS_MAXR * nkv));
-    const char* pvc_env = getenv("MTTS_PV_COMBINE");
-    const bool pvc = !pvc_env || atoi(pvc_env) != 0;
-    for (int rep = 0; rep < (pvc ? 2 : 1); ++rep) {
-        if (rep) HIPCHK(hipMemsetAsync(outp, 0, (size_t)MTTS_MAXR * nq * MTTS_HD * 2, st));
-        if (launch_attn(dev_q, kc, vc, pt, meta, scores, stats, opart, outp, MTTS_MAXR, pages_bound, max_pages, total_pages, nch, nq, nkv,
-                        scale, nullptr, arrive, pvc ? 1 : 0, st))
-            return fail(MTTS_EINVAL, "attention group size not built (1, 2, 4)");
-        if (pvc) launch_attn(dev_q, kc, vc, pt, meta, scores, stats, opart, outp, MTTS_MAXR, pages_bound, max_pages, total_pages, nch, nq, nkv,
-                             scale, nullptr, arrive, 4, st);
-    }
+    if (launch_attn(dev_q, kc, vc, pt, meta, scores, stats, opart, outp, MTTS_MAXR, pages_bound, max_pages, total_pages, nch, nq, nkv,
+                    scale, nullptr, 0, st))
+        return fail(MTTS_EINVAL, "attention group size not built (1, 2, 4)");
     launch_unpack_rows(outp, dev_out, R, nq * MTTS_HD, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(meta); hipFree(pt); hipFree(lens); hipFree(kc); hipFree(vc); hipFree(scores); hipFree(stats); hipFree(opart); hipFree(outp); hipFree(arrive);
+    hipFree(meta); hipFree(pt); hipFree(lens); hipFree(kc); hipFree(vc); hipFree(scores); hipFree(stats); hipFree(opart); hipFree(outp);
     return MTTS_OK;
 }
 
@@ -1663,8 +1646,7 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
                              (const uint16_t*)e->layers[layer].kn, (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin,
                              e->cfg.rms_norm_eps};
             launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
-                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr,
-                        e->attn_arrive, (phase == 2 && e->pv_combine && e->B > e->small_rows) ? 4 : phase, nullptr);
+                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr, phase, nullptr);
         }
     };
     run(e->L);                               // warm-up

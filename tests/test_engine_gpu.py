@@ -750,47 +750,3 @@ def test_fp32_continuous_batching_equals_standalone():
     eng.close()
     solo.close()
 
-
-def test_pv_in_launch_combine_is_bit_identical(monkeypatch):
-    """Decode rows sum the P.V chunk partials inside the P.V launch (the block that takes a (row, kv head) group's last
-    ticket adds them in chunk order; MTTS_PV_COMBINE=0 runs attn_combine_kernel as a launch of its own).  Same order,
-    so the same bits: (a) the attention hook on ragged lengths up to 24 pages (3 chunks), run twice so that the
-    self-re-armed ticket counters are used a second time; (b) whole generations of a 6-row batch (the general path),
-    greedy and sampled, 150 steps across page boundaries, fused and un-fused q/k/v epilogue."""
-    from mtts.engine import Engine
-    lib = capi.lib()
-    rng = np.random.default_rng(23)
-    R, Lmax, nq, nkv = 7, 1500, 8, 4
-    lens = np.array([1500, 1, 64, 65, 777, 1023, 512], dtype=np.int32)
-    q = _bf16_t(rng.standard_normal((R, nq, 128)).astype(np.float32))
-    K = _bf16_t(rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32))
-    V = _bf16_t(rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32))
-    table = rng.permutation(R * ((Lmax + 63) // 64)).astype(np.int32).reshape(R, -1)
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("MTTS_PV_COMBINE", flag)
-        o = torch.zeros(R, nq * 128, dtype=torch.bfloat16, device="cuda")
-        capi.check(lib.mtts_k_paged_attn_decode(q.data_ptr(), K.data_ptr(), V.data_ptr(), lens.ctypes.data, table.ctypes.data,
-                                                R, Lmax, nq, nkv, o.data_ptr(), None))
-        torch.cuda.synchronize()
-        outs.append(o)
-    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().sum()) > 0
-    cfg = synth.tiny()
-    w = synth.synth_weights(cfg, 261, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
-    ids, mask = synth.synth_prompts(cfg, 262, 6, 60, 0.4, True)
-    max_length = ids.shape[1] + 150
-    layers = [dict(top_k=40, top_p=0.9, temperature=1.1, repetition_penalty=1.05)] * 8
-    res = {}
-    for flag in ("1", "0"):
-        for fuse in ("1000000", "0"):
-            monkeypatch.setenv("MTTS_PV_COMBINE", flag)
-            monkeypatch.setenv("MTTS_FUSE_QKV_MAX", fuse)
-            eng = Engine(cfg, max_batch=8, max_seq_len=320)
-            eng.bind_state_dict(w)
-            res[(flag, fuse)] = (eng.generate(ids, mask, max_length),
-                                 eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=5))
-            eng.close()
-    ref = res[("0", "0")]
-    assert ref[0].shape[1] - (ids.shape[1] - 7) > 120
-    for k, v in res.items():
-        assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]), k
