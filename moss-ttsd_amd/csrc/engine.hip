@@ -52,7 +52,7 @@ int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* pag
                 const QkvFuse* fuse, int phase, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
 struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, logits_f32; };
-struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; };
+struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; uint32_t* nuc_cnt; unsigned long long* nuc_mass; };
 #define SAMP_CAND 4096
 #define SAMP_NS 32
 void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, int Vs_pad, const uint32_t* bitmaps,
@@ -178,7 +178,7 @@ struct MttsEngine {
     uint32_t* d_bitmaps = nullptr;
     int bm_words = 0;
     MttsSamplerCfg* d_scfg = nullptr;
-    SampleScratch sscr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SampleScratch sscr = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int ch0_sampled = 0;
     int32_t* d_pf_tokens = nullptr;     // prefill staging
     RowMeta* d_pf_meta = nullptr;
@@ -224,11 +224,13 @@ static int dalloc(T** p, size_t n, bool zero = true) {
 
 static int alloc_scratch(SampleScratch& sc, int rows, int vocab) {
     const int fc = full_cap_for(vocab);
-    sc.full_val = nullptr; sc.full_idx = nullptr;
+    sc.full_val = nullptr; sc.full_idx = nullptr; sc.nuc_cnt = nullptr; sc.nuc_mass = nullptr;
     TRY(dalloc(&sc.overflow, (size_t)rows));
-    if (fc) {            // full-vocabulary sort space (sampling without top_k): rows x next_pow2(vocab) pairs
+    if (fc) {            // full-vocabulary path (sampling without top_k): per token a key and a level-0 bin, per row the level-0 histogram
         TRY(dalloc(&sc.full_val, (size_t)rows * fc, false));
         TRY(dalloc(&sc.full_idx, (size_t)rows * fc, false));
+        TRY(dalloc(&sc.nuc_cnt, (size_t)rows * 2048));
+        TRY(dalloc(&sc.nuc_mass, (size_t)rows * 2048));
     }
     TRY(dalloc(&sc.hist, (size_t)rows * 2048));
     TRY(dalloc(&sc.slice_val, (size_t)rows * SAMP_NS));
@@ -241,7 +243,7 @@ static int alloc_scratch(SampleScratch& sc, int rows, int vocab) {
 static void free_scratch(SampleScratch& sc) {
     hipFree(sc.hist); hipFree(sc.slice_val); hipFree(sc.slice_idx); hipFree(sc.cand_val); hipFree(sc.cand_idx); hipFree(sc.cand_n);
     hipFree(sc.overflow);
-    if (sc.full_val) { hipFree(sc.full_val); hipFree(sc.full_idx); }
+    if (sc.full_val) { hipFree(sc.full_val); hipFree(sc.full_idx); hipFree(sc.nuc_cnt); hipFree(sc.nuc_mass); }
 }
 
 // ---- KV page pool -----------------------------------------------------------------------------------------------

@@ -102,8 +102,10 @@ struct SampleScratch {
     int32_t* cand_idx;     // [32][SAMP_CAND]
     uint32_t* cand_n;      // [rows]
     int32_t* overflow;     // [rows] set by the final kernel when a row needs the full-vocabulary path
-    float* full_val;       // [rows][full_cap]
-    int32_t* full_idx;     // [rows][full_cap]
+    float* full_val;       // [rows][full_cap]   full-vocabulary path: level-0 bin (uint16) of every token
+    int32_t* full_idx;     // [rows][full_cap]   full-vocabulary path: key of every token
+    uint32_t* nuc_cnt;     // [rows][2048] level-0 histogram (count) left by the collect kernel for the full-vocabulary kernel
+    unsigned long long* nuc_mass;   // [rows][2048] ... and mass (exp(s - max) * 2^45, exact integer sums)
 };
 
 struct SampleCtx {         // resolved per (row, channel)
@@ -201,6 +203,46 @@ __global__ __launch_bounds__(SAMP_T) void sample_scan_kernel(
             if (hist[i]) atomicAdd(&sc.hist[(size_t)b * 2048 + i], hist[i]);
 }
 
+// ---- helpers of the full-vocabulary path (sample_full_kernel below; its first pass runs inside sample_collect_kernel)
+#define SAMP_FT 1024
+#define NUC_BINS 2048
+#define NUC_SCALE 35184372088832.0          // 2^45
+typedef unsigned long long u64;
+
+struct NucSel {            // membership of the current candidate set, in (key, id) order
+    uint32_t kmin;         // survivors of top-k: key >= kmin (and finite)
+    uint32_t kp;           // kept by top-p: key > kp, or key == kp and id >= idp
+    int idp;
+};
+__device__ __forceinline__ float unfkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ bool nuc_in(const NucSel& z, uint32_t key, int id) {
+    return key > 0x007fffffu /* fkey(-inf) */ && key >= z.kmin && (key > z.kp || (key == z.kp && id >= z.idp));
+}
+__device__ __forceinline__ int nuc_bin(uint32_t key, float lo) {
+    const int b = (int)((unfkey(key) - lo) * ((float)(NUC_BINS - 1) / 32.0f));      // monotone in the score
+    return min(max(b, 0), NUC_BINS - 1);
+}
+
+__device__ __forceinline__ u64 nuc_q(uint32_t key, float smax) { return (u64)((double)expf(unfkey(key) - smax) * NUC_SCALE); }
+
+// Pass A for tokens i0, i0 + step, ... < i1 of one row: processed score -> key + level-0 bin (scratch, read by every later
+// pass) and the level-0 histogram in LDS (cnt / mass: 2048 entries each, zeroed by the caller).
+__device__ __forceinline__ void nuc_pass_a(const SampleCtx& x, float smax, float lo, uint32_t* __restrict__ keys,
+                                           uint16_t* __restrict__ bins, unsigned int* cnt, u64* mass, int i0, int i1, int step) {
+    for (int i = i0; i < i1; i += step) {
+        const float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp) + 0.0f;      // (-0 -> +0: one key per value)
+        const uint32_t key = fkey(s);
+        keys[i] = key;
+        if (s > -INFINITY) {
+            const int d = nuc_bin(key, lo);
+            bins[i] = (uint16_t)d;
+            atomicAdd(&cnt[d], 1u);
+            atomicAdd(&mass[d], nuc_q(key, smax));
+        } else bins[i] = 0xffffu;
+    }
+}
+
+
 // Bin of the k-th largest score in a 2048-bin histogram of fkey(score) >> 21 (LDS or global), SAMP_T threads:
 // thread t owns bins 8t..8t+7; suffix sums over lanes and waves locate the bin.  Result in every thread.
 __device__ __forceinline__ int topk_bin(const uint32_t* hist, uint32_t k, uint32_t* wsum, int* sh_b0) {
@@ -235,7 +277,7 @@ __device__ __forceinline__ int topk_bin(const uint32_t* hist, uint32_t k, uint32
 __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
     const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
-    SampleScratch sc, int single_vocab,
+    SampleScratch sc, int full_cap, int single_vocab,
     int single_mask, int single_step, int single_channel) {
     __shared__ uint32_t wsum[SAMP_T / 64];
     __shared__ int sh_b0;
@@ -245,10 +287,27 @@ __global__ __launch_bounds__(SAMP_T) void sample_collect_kernel(
                     single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
     if (!cfg.do_sample) return;
-    int b0 = 0;                                   // no top-k: every finite score is a candidate
-    if (cfg.top_k > 0 && cfg.top_k < x.V) {
-        b0 = topk_bin(sc.hist + (size_t)b * 2048, (uint32_t)cfg.top_k, wsum, &sh_b0);
+    // no top-k (every finite score is a candidate) or a top_k beyond the candidate buffer: nothing to collect, the row
+    // goes to the full-vocabulary kernel (the final kernel flags it when it sees more than SAMP_CAND candidates)
+    if (!(cfg.top_k > 0 && cfg.top_k < x.V) || cfg.top_k > SAMP_CAND) {
+        // ... whose first pass over the row (keys, level-0 bins, level-0 histogram) is done HERE, by the row's 32 blocks
+        __shared__ unsigned int a_cnt[2048];
+        __shared__ unsigned long long a_mass[2048];
+        float smax = sc.slice_val[b * SAMP_NS + (lane & (SAMP_NS - 1))];
+        smax = wave_max(smax);
+        for (int i = tid; i < 2048; i += SAMP_T) { a_cnt[i] = 0; a_mass[i] = 0; }
+        __syncthreads();
+        const int per = (x.V + SAMP_NS - 1) / SAMP_NS;
+        const int i0 = slice * per, i1 = min(x.V, i0 + per);
+        nuc_pass_a(x, smax, smax - 32.0f, (uint32_t*)(sc.full_idx + (size_t)b * full_cap), (uint16_t*)(sc.full_val + (size_t)b * full_cap),
+                   a_cnt, a_mass, i0 + tid, i1, SAMP_T);
+        __syncthreads();
+        for (int i = tid; i < 2048; i += SAMP_T)
+            if (a_cnt[i]) { atomicAdd(&sc.nuc_cnt[(size_t)b * 2048 + i], a_cnt[i]); atomicAdd(&sc.nuc_mass[(size_t)b * 2048 + i], a_mass[i]); }
+        if (slice == 0 && tid == 0) { sc.cand_n[b] = SAMP_CAND + 1; sc.overflow[b] = 2; }
+        return;
     }
+    const int b0 = topk_bin(sc.hist + (size_t)b * 2048, (uint32_t)cfg.top_k, wsum, &sh_b0);
     const uint32_t ninf_key = fkey(-INFINITY);
     const int per = (x.V + SAMP_NS - 1) / SAMP_NS;
     const int i0 = slice * per, i1 = min(x.V, i0 + per);
@@ -445,7 +504,7 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
         return;
     }
     if (n > SAMP_CAND || n == 0) {               // too many candidates: hand the row to the full-vocabulary kernel
-        if (tid == 0) { decisions[out_slot] = amax; if (n > SAMP_CAND) sc.overflow[b] = 1; }
+        if (tid == 0) { decisions[out_slot] = amax; if (n > SAMP_CAND && sc.overflow[b] == 0) sc.overflow[b] = 1; }
         return;
     }
     const int pick = finish_sample<SAMP_T>(cval, cidx, n, cfg, smax, (uint32_t)x.step, x.row_id, (uint32_t)x.c,
@@ -453,43 +512,268 @@ __global__ __launch_bounds__(SAMP_T) void sample_final_kernel(
     if (tid == 0) decisions[out_slot] = pick;
 }
 
-// Full-vocabulary path (no top_k, or more than SAMP_CAND candidates): same rules on the whole row, sorted in
-// global memory by one 1024-thread block per row.  Runs only for rows the final kernel flagged.
-#define SAMP_FT 1024
+// ---------------------------------------------------------------------------------------------------------------
+// Full-vocabulary path (sampling without top_k, or a top_k beyond the candidate buffer): the same HF rules and the same
+// draw as finish_sample, WITHOUT sorting the row.  In the order (score asc, id asc) every quantity the rules need is
+// a position found by counting or by mass: the k-th largest score (top-k threshold), the longest prefix whose
+// cumulative softmax mass is <= 1 - top_p, and the token at which the running mass from the top exceeds u * total.
+// Each is located by radix selection: a 2048-bin histogram (count + mass) over a linear binning of the score, then the
+// three digits (11 | 11 | 10 bits) of the order-preserving key inside the crossing bin, then -- among tokens of EQUAL
+// score -- two 9-bit digits of the token id.  One 1024-thread block per row, ~11 passes over the row's keys (L2
+// resident), against the 171 global-memory bitonic passes over 2^18 slots this replaces (17 ms -> tens of us).
+// Masses are exact integers (exp(s - max) * 2^45, uint64): sums do not depend on the order of the LDS atomics, so the
+// pick is reproducible; against the fp64 sums of the in-block path / the oracle they differ by < 1e-8 of the total.
+// ---------------------------------------------------------------------------------------------------------------
+struct NucShared {
+    unsigned int cnt0[NUC_BINS];      // level-0 histogram (linear score bins) of the CURRENT candidate set
+    u64 mass0[NUC_BINS];
+    unsigned int cnt[NUC_BINS];       // digit histograms of the passes below
+    u64 mass[NUC_BINS];
+    u64 wm[SAMP_FT / 64];
+    unsigned int wc[SAMP_FT / 64];
+    int cross;
+    unsigned int out_cnt, grp_cnt;
+    u64 out_mass, grp_mass;
+};
+// One digit pass over the row, restricted to the tokens of level-0 bin `binA` that are members of `z`.
+// level 1..3: key digits (higher digits == `prefix`); 4, 5: id digits (9 bits each) of the tokens whose key == `prefix`.
+__device__ void nuc_hist(NucShared& S, const uint32_t* __restrict__ keys, const uint16_t* __restrict__ bins, int V, const NucSel& z,
+                         float smax, int level, int binA, uint32_t prefix, int idhi) {
+    for (int i = threadIdx.x; i < NUC_BINS; i += SAMP_FT) { S.cnt[i] = 0; S.mass[i] = 0; }
+    __syncthreads();
+    // The bins are read 8 per 16-byte load, four loads in flight per thread (a load-test-loop pays one L2 round trip per
+    // token); almost every group holds no token of bin `binA` and leaves after one packed compare.
+    const int G = (V + 7) >> 3;                           // (bins[V .. 8G) hold 0xffff: sample_full_kernel pads them)
+    const u32x4_t* bv = (const u32x4_t*)bins;
+    const uint32_t pat = (uint32_t)binA * 0x00010001u;
+    auto member = [&](int i) {
+        const uint32_t key = keys[i];
+        if (!nuc_in(z, key, i)) return;
+        int d;
+        if (level == 1) d = key >> 21;
+        else if (level == 2) { if ((key >> 21) != prefix) return; d = (key >> 10) & 2047; }
+        else if (level == 3) { if ((key >> 10) != prefix) return; d = key & 1023; }
+        else {
+            if (key != prefix) return;
+            if (level == 4) d = i >> 9;
+            else { if ((i >> 9) != idhi) return; d = i & 511; }
+        }
+        atomicAdd(&S.cnt[d], 1u);
+        if (level <= 3) atomicAdd(&S.mass[d], nuc_q(key, smax));
+    };
+    for (int g0 = threadIdx.x; g0 < G; g0 += SAMP_FT * 4) {
+        u32x4_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + u * SAMP_FT;
+            w[u] = g < G ? bv[g] : u32x4_t{~0u, ~0u, ~0u, ~0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + u * SAMP_FT;
+            const uint32_t ww[4] = {w[u].x ^ pat, w[u].y ^ pat, w[u].z ^ pat, w[u].w ^ pat};
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) any |= (ww[k] - 0x00010001u) & ~ww[k] & 0x80008000u;    // a zero half-word somewhere?
+            if (!any) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((ww[k] & 0xffffu) == 0) member(8 * g + 2 * k);
+                if ((ww[k] >> 16) == 0) member(8 * g + 2 * k + 1);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Walk the bins of (cnt, mass) in ascending (asc) or descending order and find the first one at which `crossed(count so far
+// incl. the bin, mass so far incl. the bin)` holds (it is monotone).  `bc` / `bm` = count / mass in front of the walk; on
+// return they hold the totals in front of the crossing bin, S.grp_cnt / S.grp_mass that bin's own content.  Returns the
+// bin, or -1 (then S.wc / S.wm hold the per-wave totals of the walk).
+template <typename F>
+__device__ int nuc_cross(NucShared& S, const unsigned int* cnt, const u64* mass, bool asc, unsigned int& bc, u64& bm, F crossed) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p0 = 2 * tid, b0 = asc ? p0 : NUC_BINS - 1 - p0, b1 = asc ? p0 + 1 : NUC_BINS - 2 - p0;
+    const unsigned int c0 = cnt[b0], c1 = cnt[b1];
+    const u64 m0 = mass[b0], m1 = mass[b1];
+    unsigned int ic = c0 + c1;
+    u64 im = m0 + m1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int tc = __shfl_up(ic, o, 64);
+        const u64 tm = __shfl_up(im, o, 64);
+        if (lane >= o) { ic += tc; im += tm; }
+    }
+    if (tid == 0) S.cross = 0x7fffffff;
+    __syncthreads();
+    if (lane == 63) { S.wc[wid] = ic; S.wm[wid] = im; }
+    __syncthreads();
+    unsigned int ec = bc + ic - (c0 + c1);
+    u64 em = bm + im - (m0 + m1);
+    for (int w = 0; w < wid; ++w) { ec += S.wc[w]; em += S.wm[w]; }
+    const bool x0 = (c0 > 0) && crossed(ec + c0, em + m0);
+    const bool x1 = (c1 > 0) && crossed(ec + c0 + c1, em + m0 + m1);
+    if (x0) atomicMin(&S.cross, p0);
+    else if (x1) atomicMin(&S.cross, p0 + 1);
+    __syncthreads();
+    const int px = S.cross;
+    if (px == p0) { S.out_cnt = ec; S.out_mass = em; S.grp_cnt = c0; S.grp_mass = m0; }
+    if (px == p0 + 1) { S.out_cnt = ec + c0; S.out_mass = em + m0; S.grp_cnt = c1; S.grp_mass = m1; }
+    __syncthreads();
+    if (px == 0x7fffffff) return -1;
+    bc = S.out_cnt;
+    bm = S.out_mass;
+    return asc ? px : NUC_BINS - 1 - px;
+}
+
+// Locate the crossing of `crossed` down to one key value.  false: the walk never crosses.  Else `key` = the score group (all
+// member tokens of that key), bc / bm = what lies in front of the group, gc / gm = the group's count / mass; binA = its level-0
+// bin, c_bin / m_bin = what lies in front of that bin.
+template <typename F>
+__device__ bool nuc_select_key(NucShared& S, const uint32_t* keys, const uint16_t* bins, int V, const NucSel& z, float smax, bool asc,
+                               unsigned int& bc, u64& bm, F crossed, uint32_t& key, unsigned int& gc, u64& gm, int& binA,
+                               unsigned int& c_bin, u64& m_bin) {
+    binA = nuc_cross(S, S.cnt0, S.mass0, asc, bc, bm, crossed);
+    if (binA < 0) return false;
+    c_bin = bc;
+    m_bin = bm;
+    nuc_hist(S, keys, bins, V, z, smax, 1, binA, 0, 0);
+    const int d1 = nuc_cross(S, S.cnt, S.mass, asc, bc, bm, crossed);
+    nuc_hist(S, keys, bins, V, z, smax, 2, binA, (uint32_t)d1, 0);
+    const int d2 = nuc_cross(S, S.cnt, S.mass, asc, bc, bm, crossed);
+    nuc_hist(S, keys, bins, V, z, smax, 3, binA, ((uint32_t)d1 << 11) | (uint32_t)d2, 0);
+    const int d3 = nuc_cross(S, S.cnt, S.mass, asc, bc, bm, crossed);
+    key = ((uint32_t)d1 << 21) | ((uint32_t)d2 << 10) | (uint32_t)d3;
+    gc = S.grp_cnt;
+    gm = S.grp_mass;
+    return true;
+}
+
+// Among the member tokens of key `key` (level-0 bin binA): the id at rank `rank` (0-based) in ascending / descending id order.
+__device__ int nuc_select_id(NucShared& S, const uint32_t* keys, const uint16_t* bins, int V, const NucSel& z, float smax, int binA,
+                             uint32_t key, bool asc, unsigned int rank) {
+    unsigned int bc = 0;
+    u64 bm = 0;
+    auto by_rank = [rank](unsigned int c, u64) { return c > rank; };
+    nuc_hist(S, keys, bins, V, z, smax, 4, binA, key, 0);
+    const int hi = nuc_cross(S, S.cnt, S.mass, asc, bc, bm, by_rank);
+    nuc_hist(S, keys, bins, V, z, smax, 5, binA, key, hi);
+    const int low = nuc_cross(S, S.cnt, S.mass, asc, bc, bm, by_rank);
+    return (hi << 9) | low;
+}
+
+// The level-0 histogram after `dc` tokens / `dm` mass have left from the bottom of the order, the last of them inside bin
+// binA (c_bin / m_bin = what lay in front of that bin).
+__device__ void nuc_drop_prefix(NucShared& S, int binA, unsigned int dc, u64 dm, unsigned int c_bin, u64 m_bin) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < binA; i += SAMP_FT) { S.cnt0[i] = 0; S.mass0[i] = 0; }
+    if (threadIdx.x == 0) { S.cnt0[binA] -= dc - c_bin; S.mass0[binA] -= dm - m_bin; }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(SAMP_FT) void sample_full_kernel(
     const uint16_t* __restrict__ logits0, int V0, const uint32_t* __restrict__ bitmaps, int bm_words,
     const MttsSamplerCfg* __restrict__ cfgs, const LoopState* __restrict__ ls, const SeqState* __restrict__ seqs,
     uint64_t seed, int32_t* __restrict__ decisions, SampleScratch sc, int full_cap, int single_vocab, int single_mask, int single_step,
     int single_channel) {
+    __shared__ NucShared S;
     __shared__ float shf[SAMP_FT / 64];
-    __shared__ double shd[SAMP_FT / 64];
     __shared__ int shi[SAMP_FT / 64];
-    __shared__ int sh_i[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (!sc.overflow[b]) return;
+    const int flag = sc.overflow[b];
+    if (!flag) return;
     SampleCtx x;
     if (!sample_ctx(x, b, 0, logits0, nullptr, V0, 0, 0, bitmaps, bm_words, cfgs, ls, seqs, single_vocab, single_mask,
                     single_step, single_channel)) return;
     const MttsSamplerCfg cfg = cfgs[x.c];
-    float* val = sc.full_val + (size_t)b * full_cap;
-    int* idx = sc.full_idx + (size_t)b * full_cap;
+    uint16_t* bins = (uint16_t*)(sc.full_val + (size_t)b * full_cap);  // level-0 bin of every token (0xffff: -inf)
+    uint32_t* keys = (uint32_t*)(sc.full_idx + (size_t)b * full_cap);  // order-preserving key of every processed score
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (tid < SAMP_NS) { bv = sc.slice_val[b * SAMP_NS + tid]; bi = sc.slice_idx[b * SAMP_NS + tid]; }
     block_argmax(bv, bi, shf, shi);
     const float smax = bv;
-    // compact the finite scores (ascending id per thread chunk; order is fixed by the sort anyway)
-    if (tid == 0) sh_i[0] = 0;
-    __syncthreads();
-    for (int i = tid; i < x.V; i += SAMP_FT) {
-        const float s = proc_score(x.lg, i, x.mask_id, x.bm, x.penalty, x.temp);
-        if (s > -INFINITY) { const int slot = atomicAdd(&sh_i[0], 1); val[slot] = s; idx[slot] = i; }
+    const float lo = smax - 32.0f;
+    const int V = x.V;
+    // ---- level-0 histogram: left by the collect kernel's 32 blocks per row (flag 2), or built here (a row that overflowed
+    // the candidate buffer although its top_k fits: many tokens tie with the k-th score)
+    if (flag == 2) {
+        unsigned int* gc_ = sc.nuc_cnt + (size_t)b * NUC_BINS;
+        u64* gm_ = sc.nuc_mass + (size_t)b * NUC_BINS;
+        for (int i = tid; i < NUC_BINS; i += SAMP_FT) { S.cnt0[i] = gc_[i]; S.mass0[i] = gm_[i]; gc_[i] = 0; gm_[i] = 0; }
+        __syncthreads();
+    } else {
+        for (int i = tid; i < NUC_BINS; i += SAMP_FT) { S.cnt0[i] = 0; S.mass0[i] = 0; }
+        __syncthreads();
+        nuc_pass_a(x, smax, lo, keys, bins, S.cnt0, S.mass0, tid, V, SAMP_FT);
+        __syncthreads();
     }
+    if (tid < 8 && V + tid < ((V + 7) & ~7)) bins[V + tid] = 0xffffu;   // the digit passes read the bins 8 at a time
     __syncthreads();
-    const int n = sh_i[0];
-    __syncthreads();
+    unsigned int n = 0;
+    u64 tot = 0;
+    {
+        unsigned int bc = 0; u64 bm = 0;
+        auto never = [](unsigned int, u64) { return false; };
+        (void)nuc_cross(S, S.cnt0, S.mass0, true, bc, bm, never);      // no crossing: the walk's per-wave sums are the totals
+        for (int w = 0; w < SAMP_FT / 64; ++w) { n += S.wc[w]; tot += S.wm[w]; }
+        __syncthreads();
+    }
     int pick = bi;
-    if (n > 0) pick = finish_sample<SAMP_FT>(val, idx, n, cfg, smax, (uint32_t)x.step, x.row_id, (uint32_t)x.c,
-                                            single_vocab > 0 ? seed : x.seed, shd, sh_i);
+    if (n > 0) {
+        NucSel z{0u, 0u, 0};
+        int binA; unsigned int c_bin; u64 m_bin;
+        // ---- top-k (HF TopKLogitsWarper): scores below the k-th largest go; ties with it stay
+        if (cfg.top_k > 0 && (unsigned int)cfg.top_k < n) {
+            const unsigned int idx0 = n - (unsigned int)cfg.top_k;       // ascending position of the k-th largest
+            unsigned int bc = 0, gc; u64 bm = 0, gm; uint32_t kk;
+            auto at = [idx0](unsigned int c, u64) { return c > idx0; };
+            nuc_select_key(S, keys, bins, V, z, smax, true, bc, bm, at, kk, gc, gm, binA, c_bin, m_bin);
+            z.kmin = kk;
+            n -= bc;                                        // everything in front of the threshold's group is dropped
+            tot -= bm;
+            nuc_drop_prefix(S, binA, bc, bm, c_bin, m_bin);
+        }
+        // ---- top-p (HF TopPLogitsWarper): longest ascending prefix with cumulative softmax <= 1 - top_p goes
+        if (cfg.top_p > 0.f && cfg.top_p < 1.0f) {
+            const double dtot = (double)tot;
+            const float omp = cfg.one_minus_top_p;
+            auto beyond = [dtot, omp](unsigned int, u64 m) { return !((float)((double)m / dtot) <= omp); };
+            unsigned int bc = 0, gc; u64 bm = 0, gm; uint32_t kp;
+            if (nuc_select_key(S, keys, bins, V, z, smax, true, bc, bm, beyond, kp, gc, gm, binA, c_bin, m_bin)) {
+                // tokens of equal score leave in ascending id order: t of the group's gc go (t < gc: the group crosses)
+                const u64 q = gm / gc;
+                unsigned int t = 0, hi = gc;                // largest t with cum(bm + t q) <= 1 - p
+                while (t < hi) {
+                    const unsigned int mid = (t + hi + 1) >> 1;
+                    if (!beyond(0u, bm + (u64)mid * q)) t = mid; else hi = mid - 1;
+                }
+                int idp = 0;
+                if (t > 0) idp = nuc_select_id(S, keys, bins, V, z, smax, binA, kp, true, t);      // the (t+1)-th smallest id stays
+                z.kp = kp;
+                z.idp = idp;
+                n -= bc + t;
+                tot -= bm + (u64)t * q;
+                nuc_drop_prefix(S, binA, bc + t, bm + (u64)t * q, c_bin, m_bin);
+            }
+        }
+        // ---- draw: walk the kept tokens from the top; the first whose running mass exceeds u * total
+        uint32_t rnd[4];
+        const uint64_t sd = single_vocab > 0 ? seed : x.seed;
+        philox4x32_10((uint32_t)x.step, x.row_id, (uint32_t)x.c, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), rnd);
+        const double u = (double)((float)(rnd[0] >> 8) * (1.0f / 16777216.0f));
+        const double target = u * ((double)tot / NUC_SCALE);
+        auto past = [target](unsigned int, u64 m) { return (double)m / NUC_SCALE > target; };
+        unsigned int bc = 0, gc; u64 bm = 0, gm; uint32_t kd;
+        if (nuc_select_key(S, keys, bins, V, z, smax, false, bc, bm, past, kd, gc, gm, binA, c_bin, m_bin)) {
+            const u64 q = gm / gc;
+            unsigned int j = 1, hi = gc;                    // smallest j with mass(bm + j q) past the target (ties: higher id first)
+            while (j < hi) {
+                const unsigned int mid = (j + hi) >> 1;
+                if (past(0u, bm + (u64)mid * q)) hi = mid; else j = mid + 1;
+            }
+            pick = nuc_select_id(S, keys, bins, V, z, smax, binA, kd, false, j - 1);
+        }
+    }
     if (tid == 0) { decisions[b * 8 + x.c] = pick; sc.overflow[b] = 0; }
 }
 
@@ -614,7 +898,7 @@ void launch_sample(const void* logits0, const void* logits17, int V0, int Vs, in
                            bitmaps, bm_words, cfgs, ls, seqs, sc, 0, 0, 0, 0);
         if (ch0_sampled)
             hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0, V0,
-                               bitmaps, bm_words, cfgs, ls, seqs, sc, 0, 0, 0, 0);
+                               bitmaps, bm_words, cfgs, ls, seqs, sc, full_cap, 0, 0, 0, 0);
     }
     hipLaunchKernelGGL(sample_final_kernel, dim3(8, B), dim3(SAMP_T), 0, st, (const uint16_t*)logits0,
                        (const uint16_t*)logits17, V0, Vs, Vs_pad, bitmaps, bm_words, cfgs, ls, seqs, seed, decisions, err, sc,
@@ -630,7 +914,7 @@ void launch_sample_single(const void* logits, int rows, int vocab, const uint32_
         hipLaunchKernelGGL(sample_scan_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
                            bitmap, bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, sc, vocab, mask_id, step, channel);
         hipLaunchKernelGGL(sample_collect_kernel, dim3(SAMP_NS, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits, vocab,
-                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, sc, vocab, mask_id, step, channel);
+                           bitmap, bm_words, cfgs8, (const LoopState*)nullptr, (const SeqState*)nullptr, sc, full_cap, vocab, mask_id, step, channel);
     }
     hipLaunchKernelGGL(sample_final_kernel, dim3(1, rows), dim3(SAMP_T), 0, st, (const uint16_t*)logits,
                        (const uint16_t*)nullptr, vocab, vocab, vocab, bitmap, bm_words, cfgs8, (const LoopState*)nullptr,
