@@ -64,6 +64,8 @@ typedef struct MttsConfig {
 } MttsConfig;
 #define MTTS_DTYPE_BF16 0
 #define MTTS_DTYPE_F32 1
+#define MTTS_DTYPE_F16 2   /* `--dtype fp16`: the MTTS_DTYPE_F32 kernels with an fp16 rounding point wherever the reference's fp16
+                              run materialises a tensor; weights / RoPE tables are bound as fp32 tensors holding fp16 values */
 
 /* generation_config.layers[i] / do_samples[i] (modeling_asteroid.py:95-106).
  * A field <= 0 (or top_k == 0) means "processor absent". */

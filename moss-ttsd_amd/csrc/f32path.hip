@@ -10,7 +10,16 @@
 // The kernels are plain and HBM-bound on the fp32 weights (6.9 GB per decode step at the ASSUMED dims); the tuned path
 // is the bf16 one.  Products and sums that the reference does as separate fp32 operations are kept separate
 // (__fmul_rn / __fadd_rn) where an FMA contraction would otherwise change the rounding.
+//
+// `--dtype fp16` (the third value inference.py offers) runs the SAME kernels with `h16` set: weights arrive as fp16 values
+// (held in fp32, exact) and every tensor the reference materialises in fp16 -- each Linear output, each elementwise
+// result, the attention scores / probabilities / output -- is rounded to fp16 where torch's fp16 CPU kernels round it
+// (r16 below; the same points at which the bf16 kernels round to bf16).  Accumulations stay fp32, as torch's do.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
+
+__device__ __forceinline__ float r16(float v, int h16) { return h16 ? __half2float(__float2half_rn(v)) : v; }
 
 __device__ __forceinline__ float block_sum_256f(float v, float* sh) {
     v = wave_sum(v);
@@ -32,7 +41,7 @@ __device__ __forceinline__ float block_max_256f(float v, float* sh) {
 // x[r] = sum_c emb_c[tok_c] (zeros, then += in channel order); xn = w * (x * rsqrt(mean(x^2) + eps)).  grid R, block 256.
 __global__ __launch_bounds__(256) void f32_embed_norm_kernel(const int32_t* __restrict__ tokens, const RowMeta* __restrict__ meta,
                                                              const float* const* __restrict__ tables, const float* __restrict__ norm_w,
-                                                             float* __restrict__ x, float* __restrict__ xn, int H, float eps) {
+                                                             float* __restrict__ x, float* __restrict__ xn, int H, float eps, int h16) {
     __shared__ float sh[4];
     const int r = blockIdx.x;
     const bool active = meta[r].seq >= 0;
@@ -40,30 +49,30 @@ __global__ __launch_bounds__(256) void f32_embed_norm_kernel(const int32_t* __re
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = 0.f;
         if (active)
-            for (int c = 0; c < 8; ++c) v = __fadd_rn(v, tables[c][(size_t)tokens[r * 8 + c] * H + i]);
+            for (int c = 0; c < 8; ++c) v = r16(__fadd_rn(v, tables[c][(size_t)tokens[r * 8 + c] * H + i]), h16);
         x[(size_t)r * H + i] = v;
         ss += v * v;
     }
     const float inv = rsqrtf(block_sum_256f(ss, sh) / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) xn[(size_t)r * H + i] = norm_w[i] * __fmul_rn(x[(size_t)r * H + i], inv);
+    for (int i = threadIdx.x; i < H; i += 256) xn[(size_t)r * H + i] = r16(norm_w[i] * r16(__fmul_rn(x[(size_t)r * H + i], inv), h16), h16);
 }
 
 // x += y; xn = RMSNorm(x) * w; rows flagged `last` also keep xn in hlast[seq].  grid R, block 256.
 __global__ __launch_bounds__(256) void f32_resid_norm_kernel(const float* __restrict__ y, float* __restrict__ x,
                                                              const float* __restrict__ norm_w, float* __restrict__ xn,
-                                                             float* __restrict__ hlast, const RowMeta* __restrict__ meta, int H, float eps) {
+                                                             float* __restrict__ hlast, const RowMeta* __restrict__ meta, int H, float eps, int h16) {
     __shared__ float sh[4];
     const int r = blockIdx.x;
     const RowMeta m = meta[r];
     float ss = 0.f;
     for (int i = threadIdx.x; i < H; i += 256) {
-        const float v = __fadd_rn(x[(size_t)r * H + i], y[(size_t)r * H + i]);
+        const float v = r16(__fadd_rn(x[(size_t)r * H + i], y[(size_t)r * H + i]), h16);
         x[(size_t)r * H + i] = v;
         ss += v * v;
     }
     const float inv = rsqrtf(block_sum_256f(ss, sh) / (float)H + eps);
     for (int i = threadIdx.x; i < H; i += 256) {
-        const float o = norm_w[i] * __fmul_rn(x[(size_t)r * H + i], inv);
+        const float o = r16(norm_w[i] * r16(__fmul_rn(x[(size_t)r * H + i], inv), h16), h16);
         xn[(size_t)r * H + i] = o;
         if (hlast && m.seq >= 0 && m.last) hlast[(size_t)m.seq * H + i] = o;
     }
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(256) void f32_resid_norm_kernel(const float* __rest
 // (each W row is read once, 16 B per lane per step); X rows come from L1/L2.  grid ceil(N / (4*CPW)), block 256.
 #define F32_CPW 4
 __global__ __launch_bounds__(256) void f32_gemv_kernel(const float* __restrict__ W, const float* __restrict__ X,
-                                                       float* __restrict__ Y, int R, int N, int K, long ldy) {
+                                                       float* __restrict__ Y, int R, int N, int K, long ldy, int h16) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + wave) * F32_CPW;
     if (n0 >= N) return;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void f32_gemv_kernel(const float* __restrict__
         for (int r = 0; r < 8; ++r) {
             if (r < R) {
                 const float s = wave_sum(acc[c][r]);
-                if (lane == 0 && n0 + c < N) Y[(size_t)r * ldy + n0 + c] = s;
+                if (lane == 0 && n0 + c < N) Y[(size_t)r * ldy + n0 + c] = r16(s, h16);
             }
         }
 }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void f32_qkv_post_kernel(const float* __restri
                                                            const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                            float* __restrict__ qbuf, float* __restrict__ kcache, float* __restrict__ vcache,
                                                            const int32_t* __restrict__ page_table, int max_pages, int total_pages,
-                                                           int nq, int nkv, float eps) {
+                                                           int nq, int nkv, float eps, int h16) {
     const int r = blockIdx.x, h = blockIdx.y * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (h >= nq + 2 * nkv) return;
     const RowMeta m = meta[r];
@@ -133,12 +142,12 @@ __global__ __launch_bounds__(256) void f32_qkv_post_kernel(const float* __restri
     }
     const float* nw = h < nq ? qnw : knw;
     const float inv = rsqrtf(wave_sum(a * a + b * b) / (float)MTTS_HD + eps);
-    a = nw[l] * __fmul_rn(a, inv);
-    b = nw[l + 64] * __fmul_rn(b, inv);
+    a = r16(nw[l] * r16(__fmul_rn(a, inv), h16), h16);
+    b = r16(nw[l + 64] * r16(__fmul_rn(b, inv), h16), h16);
     const float c = rope_cos[(size_t)m.pos * 64 + l], s = rope_sin[(size_t)m.pos * 64 + l];
     // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
-    const float o1 = __fadd_rn(__fmul_rn(a, c), __fmul_rn(-b, s));
-    const float o2 = __fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s));
+    const float o1 = r16(__fadd_rn(r16(__fmul_rn(a, c), h16), r16(__fmul_rn(-b, s), h16)), h16);
+    const float o2 = r16(__fadd_rn(r16(__fmul_rn(b, c), h16), r16(__fmul_rn(a, s), h16)), h16);
     float* dst = h < nq ? qbuf + ((size_t)r * nq + h) * MTTS_HD
                         : kcache + (((size_t)(h - nq) * total_pages + page) * MTTS_PAGE + tok) * MTTS_HD;
     dst[l] = o1;
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void f32_attn_kernel(const float* __restrict__
                                                        const float* __restrict__ vcache, const int32_t* __restrict__ page_table,
                                                        const RowMeta* __restrict__ meta, float* __restrict__ scores,
                                                        float* __restrict__ out, int max_pages, int total_pages, int nq, int nkv,
-                                                       float scale, int Lmax) {
+                                                       float scale, int Lmax, int h16) {
     __shared__ float sh[4];
     __shared__ float part[2][MTTS_HD];
     const int h = blockIdx.x, r = blockIdx.y;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void f32_attn_kernel(const float* __restrict__
     for (int t = wave; t < len; t += 4) {
         const float* kr = kcache + (((size_t)kvh * total_pages + pt[t >> 6]) * MTTS_PAGE + (t & 63)) * MTTS_HD;
         const float2 kv = *(const float2*)(kr + 2 * lane);
-        const float s = __fmul_rn(wave_sum(q.x * kv.x + q.y * kv.y), scale);
+        const float s = r16(__fmul_rn(r16(wave_sum(q.x * kv.x + q.y * kv.y), h16), scale), h16);
         if (lane == 0) sc[t] = s;
         mx = fmaxf(mx, s);
     }
@@ -182,53 +191,64 @@ __global__ __launch_bounds__(256) void f32_attn_kernel(const float* __restrict__
     const int d = threadIdx.x & 127, half = threadIdx.x >> 7;
     float acc = 0.f;
     for (int t = half; t < len; t += 2) {
-        const float p = sc[t] / sm;
+        const float p = r16(sc[t] / sm, h16);
         acc += p * vcache[(((size_t)kvh * total_pages + pt[t >> 6]) * MTTS_PAGE + (t & 63)) * MTTS_HD + d];
     }
     part[half][d] = acc;
     __syncthreads();
-    if (half == 0) out[((size_t)r * nq + h) * MTTS_HD + d] = part[0][d] + part[1][d];
+    if (half == 0) out[((size_t)r * nq + h) * MTTS_HD + d] = r16(part[0][d] + part[1][d], h16);
 }
 
 // act[r][i] = silu(gate) * up, gate = gu[r][i], up = gu[r][I + i]
-__global__ void f32_swiglu_kernel(const float* __restrict__ gu, float* __restrict__ act, int R, int I) {
+__global__ void f32_swiglu_kernel(const float* __restrict__ gu, float* __restrict__ act, int R, int I, int h16) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)R * I) return;
     const size_t r = idx / I, i = idx % I;
     const float g = gu[r * 2 * I + i], u = gu[r * 2 * I + I + i];
-    act[idx] = __fmul_rn(g / (1.0f + expf(-g)), u);
+    act[idx] = r16(__fmul_rn(r16(g / (1.0f + expf(-g)), h16), u), h16);
+}
+// fp16 mode, rows through the MFMA GEMM: round its fp32 outputs in place
+__global__ void f32_round16_kernel(float* __restrict__ y, int R, int N, long ldy) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)R * N) return;
+    float* p = y + (idx / N) * ldy + idx % N;
+    *p = r16(*p, 1);
 }
 
 void launch_f32_embed_norm(const int32_t* tokens, const RowMeta* meta, const float* const* tables, const float* norm_w, float* x,
-                           float* xn, int R, int H, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(f32_embed_norm_kernel, dim3(R), dim3(256), 0, st, tokens, meta, tables, norm_w, x, xn, H, eps);
+                           float* xn, int R, int H, float eps, int h16, hipStream_t st) {
+    hipLaunchKernelGGL(f32_embed_norm_kernel, dim3(R), dim3(256), 0, st, tokens, meta, tables, norm_w, x, xn, H, eps, h16);
 }
 void launch_f32_resid_norm(const float* y, float* x, const float* norm_w, float* xn, float* hlast, const RowMeta* meta, int R,
-                           int H, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(f32_resid_norm_kernel, dim3(R), dim3(256), 0, st, y, x, norm_w, xn, hlast, meta, H, eps);
+                           int H, float eps, int h16, hipStream_t st) {
+    hipLaunchKernelGGL(f32_resid_norm_kernel, dim3(R), dim3(256), 0, st, y, x, norm_w, xn, hlast, meta, H, eps, h16);
 }
 void mtts_gemm_f32_exact(hipStream_t st, const float* A, const float* W, float* C, int M, int N, int K, long ldc);   // codec.hip
 // rows are processed 8 at a time by the GEMV; bigger passes (prefill) take the exact-f32 MFMA GEMM
-void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, hipStream_t st) {
+void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, int h16, hipStream_t st) {
     if (R <= 8) {
-        hipLaunchKernelGGL(f32_gemv_kernel, dim3((N + 4 * F32_CPW - 1) / (4 * F32_CPW)), dim3(256), 0, st, W, X, Y, R, N, K, ldy);
+        hipLaunchKernelGGL(f32_gemv_kernel, dim3((N + 4 * F32_CPW - 1) / (4 * F32_CPW)), dim3(256), 0, st, W, X, Y, R, N, K, ldy, h16);
         return;
     }
     mtts_gemm_f32_exact(st, X, W, Y, R, N, K, ldy);
+    if (h16) {
+        const size_t total = (size_t)R * N;
+        hipLaunchKernelGGL(f32_round16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Y, R, N, ldy);
+    }
 }
 void launch_f32_qkv_post(const float* qkv, int ldq, const RowMeta* meta, const float* qnw, const float* knw, const float* cosb,
                          const float* sinb, float* qbuf, float* kcache, float* vcache, const int32_t* page_table, int max_pages,
-                         int total_pages, int R, int nq, int nkv, float eps, hipStream_t st) {
+                         int total_pages, int R, int nq, int nkv, float eps, int h16, hipStream_t st) {
     hipLaunchKernelGGL(f32_qkv_post_kernel, dim3(R, (nq + 2 * nkv + 3) / 4), dim3(256), 0, st, qkv, ldq, meta, qnw, knw, cosb, sinb,
-                       qbuf, kcache, vcache, page_table, max_pages, total_pages, nq, nkv, eps);
+                       qbuf, kcache, vcache, page_table, max_pages, total_pages, nq, nkv, eps, h16);
 }
 void launch_f32_attn(const float* qbuf, const float* kcache, const float* vcache, const int32_t* page_table, const RowMeta* meta,
                      float* scores, float* out, int R, int max_pages, int total_pages, int nq, int nkv, float scale, int Lmax,
-                     hipStream_t st) {
+                     int h16, hipStream_t st) {
     hipLaunchKernelGGL(f32_attn_kernel, dim3(nq, R), dim3(256), 0, st, qbuf, kcache, vcache, page_table, meta, scores, out,
-                       max_pages, total_pages, nq, nkv, scale, Lmax);
+                       max_pages, total_pages, nq, nkv, scale, Lmax, h16);
 }
-void launch_f32_swiglu(const float* gu, float* act, int R, int I, hipStream_t st) {
+void launch_f32_swiglu(const float* gu, float* act, int R, int I, int h16, hipStream_t st) {
     const size_t total = (size_t)R * I;
-    hipLaunchKernelGGL(f32_swiglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gu, act, R, I);
+    hipLaunchKernelGGL(f32_swiglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gu, act, R, I, h16);
 }

@@ -113,7 +113,7 @@ class AsteroidTTSInstruct:
         self._engine_key = None
         self.device = torch.device("cpu")
         self.training = False
-        self.dtype = "bf16"             # "fp32": the strict-parity engine (from_pretrained(torch_dtype=torch.float32))
+        self.dtype = "bf16"             # "fp32": the strict-parity engine (from_pretrained(torch_dtype=torch.float32)); "fp16": its kernels with fp16 rounding points
         self.sample_seed = None         # explicit Philox key for the next generate() (tests); None = from torch's seed
         self.sample_rows = None         # Philox row id of each row of the next generate() (a rank's share of a sharded
                                         # batch sets its rows' job-wide positions); None = 0..B-1
@@ -122,14 +122,14 @@ class AsteroidTTSInstruct:
     # ---- loading -----------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, attn_implementation=None, **_):
-        if torch_dtype not in (torch.bfloat16, torch.float32, None):
-            raise NotImplementedError("the MI355X engine is built for bf16 (the reference default) and fp32 "
-                                      f"(inference.py --dtype); torch_dtype={torch_dtype} is not")
+        if torch_dtype not in (torch.bfloat16, torch.float32, torch.float16, None):
+            raise NotImplementedError("the MI355X engine is built for the three dtypes inference.py offers (bf16, fp16, fp32); "
+                                      f"torch_dtype={torch_dtype} is not one of them")
         if not os.path.isdir(model_path):
             raise FileNotFoundError(f"{model_path}: local checkpoint directory required (no network here)")
         cfg = AsteroidTTSConfig.from_pretrained(model_path)
         m = cls(cfg, _load_safetensors_dir(model_path), GenerationConfig.from_pretrained(model_path))
-        m.dtype = "fp32" if torch_dtype == torch.float32 else "bf16"
+        m.dtype = {torch.float32: "fp32", torch.float16: "fp16"}.get(torch_dtype, "bf16")
         return m
 
     @classmethod

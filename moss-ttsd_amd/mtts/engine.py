@@ -42,10 +42,12 @@ class Engine:
     def __init__(self, cfg: dict, max_batch: int, max_seq_len: int, device="cuda:0", kv_pool_pages: int = 0, dtype="bf16"):
         """dtype "bf16" (the reference default) or "fp32" (`inference.py --dtype fp32`: fp32 weights, arithmetic,
         K/V pages and logits -- the strict-parity mode, plain HBM-bound kernels)."""
-        if dtype not in ("bf16", "fp32"):
-            raise NotImplementedError(f"dtype {dtype!r} is not built (bf16, fp32)")
+        if dtype not in ("bf16", "fp32", "fp16"):
+            raise NotImplementedError(f"dtype {dtype!r} is not built (bf16, fp32, fp16)")
         self.dtype = dtype
+        # "fp16" (`inference.py --dtype fp16`): the fp32 engine with fp16 rounding points; its tensors are fp32 holding fp16 values
         self.tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.model_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(dtype, torch.float32)
         if not torch.cuda.is_available():
             raise capi.MttsError("no GPU visible: the mtts engine only runs on MI355X (no CPU fallback)")
         self.cfg = cfg
@@ -61,10 +63,11 @@ class Engine:
         c.rms_norm_eps = float(cfg["rms_norm_eps"])
         c.max_batch, c.max_seq_len = int(max_batch), int(max_seq_len)
         c.kv_pool_pages = int(kv_pool_pages)          # 0: every slot can reach max_seq_len at once
-        c.dtype = 0 if dtype == "bf16" else 1
+        c.dtype = {"bf16": 0, "fp32": 1, "fp16": 2}[dtype]
         self._h = C.c_void_p()
         capi.check(self.lib.mtts_engine_create(C.byref(c), self.device.index or 0, C.byref(self._h)))
-        cos, sin = rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position, self.device, self.tdtype)
+        cos, sin = (t.to(self.tdtype) for t in rope_tables(cfg["head_dim"], float(cfg["rope_theta"]), c.max_position,
+                                                           self.device, self.model_dtype))
         torch.cuda.synchronize(self.device)
         capi.check(self.lib.mtts_bind_rope(self._h, cos.data_ptr(), sin.data_ptr(), c.max_position, None))
         torch.cuda.synchronize(self.device)
@@ -82,7 +85,7 @@ class Engine:
 
     # ---- weights -----------------------------------------------------------
     def bind(self, name: str, tensor: torch.Tensor):
-        t = tensor.to(device=self.device, dtype=self.tdtype).contiguous()
+        t = tensor.to(device=self.device).to(self.model_dtype).to(self.tdtype).contiguous()      # (cast like model.to(dtype) casts)
         rows, cols = (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.shape[0], 1)
         capi.check(self.lib.mtts_bind_weight(self._h, name.encode(), t.data_ptr(), rows, cols, None))
         torch.cuda.synchronize(self.device)     # the engine has packed its own copy; `t` may go
@@ -167,7 +170,7 @@ class Engine:
 
     def read_logits(self):
         V0, Vs = self.cfg["vocab_size"], self.cfg["speech_vocab_size"]
-        if self.dtype == "fp32":
+        if self.dtype != "bf16":
             l0 = np.zeros((self._B, V0), dtype=np.float32)
             l17 = np.zeros((7, self._B, Vs), dtype=np.float32)
             capi.check(self.lib.mtts_read_logits_f32(self._h, l0.ctypes.data, l17.ctypes.data, None))

@@ -54,6 +54,12 @@ def _ident(x):
     return np.asarray(x, dtype=F32)
 
 
+def round_fp16(x):
+    """fp32 -> nearest-even fp16 (overflow -> inf, as torch's cast), returned as fp32."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=F32).astype(np.float16).astype(F32)
+
+
 # --------------------------------------------------------------------------
 # Philox4x32-10 (Salmon et al. 2011), the engine's sampling stream.
 # --------------------------------------------------------------------------
@@ -162,8 +168,12 @@ class AsteroidOracle:
         self.cfg = cfg
         self.w = weights
         self.dtype = dtype
-        self.r = round_bf16 if dtype == "bf16" else _ident
-        self.neg = F32(-3.3895313892515355e38) if dtype == "bf16" else np.finfo(F32).min
+        # "fp16" (`inference.py --dtype fp16`, reference inference.py:27-40): the same rounding points with an fp16 cast;
+        # the weights arrive as fp32 and are cast like `model.to(torch.float16)` casts them
+        self.r = {"bf16": round_bf16, "fp16": round_fp16}.get(dtype, _ident)
+        if dtype == "fp16":
+            self.w = {k: round_fp16(v) for k, v in weights.items()}
+        self.neg = {"bf16": F32(-3.3895313892515355e38), "fp16": F32(-65504.0)}.get(dtype, np.finfo(F32).min)
         D = cfg["head_dim"]
         # RoPE frequencies: modeling_qwen3.py compute_default_rope_parameters
         self.inv_freq = (1.0 / (F32(cfg["rope_theta"]) ** (np.arange(0, D, 2, dtype=F32) / F32(D)))).astype(F32)

@@ -217,6 +217,8 @@ def ref_sample_loop(model, input_ids, attention_mask, max_length, layers=None, k
 
 
 def bf16_bits(t):
+    # (the stored logit slices are bf16 bit patterns in every fixture; an fp16 run's logits lose 3 mantissa bits there,
+    #  which the tests' 4-ulp-of-the-row-maximum tolerance covers)
     return t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
 
 
@@ -239,7 +241,7 @@ def make_case(name, cfg_over, wkw, seed, batch, prompt_len, audio_frac, max_new,
     steps = out.shape[1] - (ids.shape[1] - 7)
     d = dict(cfg=json.dumps(cfg), wkw=json.dumps(wkw), seed=seed, input_ids=ids, attention_mask=mask,
              max_length=max_length, out_ids=out, margins=margins.astype(np.float32),
-             layers=json.dumps(layers or []), dtype="bf16" if dtype == torch.bfloat16 else "fp32",
+             layers=json.dumps(layers or []), dtype={torch.bfloat16: "bf16", torch.float16: "fp16"}.get(dtype, "fp32"),
              transformers_version=__import__("transformers").__version__, ch0_lo=CH0_LO)
     for s in range(min(keep_steps, steps)):
         d[f"logits0_step{s}"] = logs[s][0]
@@ -346,6 +348,8 @@ if __name__ == "__main__":
         "ar_rep_penalty": ({}, hi, 404, 2, 24, 0.3, 24, dict(layers=[dict(repetition_penalty=1.3)] * 8)),
         # PRODUCTION WIDTH (round 3): the ASSUMED 1.7B layer shape -- H 2048, I 6144, 16 query / 8 KV heads x 128, the
         # full 152 697-row channel-0 table -- at 2 layers; ragged B=3, prompts of ~64 slots (text + audio tail), 24 steps
+        # fp16 model dtype (`inference.py --dtype fp16`, reference inference.py:27-40): the same stack with fp16 rounding points
+        "ar_text_ragged_fp16": ({}, lo, 103, 3, 24, 0.0, 40, dict(dtype=torch.float16)),
         "ar_wide": (WIDE, lo, 601, 3, 64, 0.3, 24, {}),
         "ar_wide_fp32": (WIDE, lo, 601, 3, 64, 0.3, 24, dict(dtype=torch.float32)),
     }

@@ -28,7 +28,7 @@ def bits_to_f32(u16):
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["ar_text_ragged_fp16"])
 def test_oracle_replay_matches_reference(golden_dir, name):
     z, cfg, w = load_case(golden_dir, name)
     orc = ao.AsteroidOracle(cfg, w, str(z["dtype"]))
@@ -56,6 +56,8 @@ def test_oracle_replay_matches_reference(golden_dir, name):
         ref = [bits_to_f32(z[f"logits0_step{s}"])] + list(bits_to_f32(z[f"logits17_step{s}"]))
         for c in range(8):
             got = logs[s][c][:, lo:] if c == 0 else logs[s][c]
+            if str(z["dtype"]) != "bf16":
+                got = ao.round_bf16(got)           # (the fixtures store every run's logits as bf16 bit patterns)
             fin = np.isfinite(ref[c])
             assert np.array_equal(np.isfinite(got), fin)
             # a dot product's error scales with the row's magnitude, not the element's:
@@ -153,7 +155,7 @@ def test_real_sample_pin_record(golden_dir):
     the three 4.53.2 helper shims) on every AR case: it must have equalled both the restated loop that wrote the
     fixtures and the committed fixtures themselves."""
     rec = json.load(open(os.path.join(golden_dir, "sample_pin.json")))
-    assert set(rec["cases"]) >= set(CASES + ["ar_text_ragged_fp32", "ar_wide_fp32"])
+    assert set(rec["cases"]) >= set(CASES + ["ar_text_ragged_fp32", "ar_wide_fp32", "ar_text_ragged_fp16"])
     for name, r in rec["cases"].items():
         assert r["real_sample_equals_restated_loop"] and r["real_sample_equals_fixture"], name
         z = np.load(os.path.join(golden_dir, name + ".npz"))

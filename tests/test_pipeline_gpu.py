@@ -173,8 +173,14 @@ def test_from_pretrained_directory_and_large_batch(tmp_path):
         short = slice(0, 32) if a.shape[1] < b.shape[1] else slice(32, 40)
         n = min(a.shape[1], b.shape[1])
         assert (o[short, n:, 0] == cfg["eos_token_id"]).all() and (o[short, n:, 1:] == 1024).all()
+    # the three dtypes inference.py offers load; anything else is refused loudly
+    m16 = AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.float16).eval().to("cuda")
+    assert m16.dtype == "fp16"
+    o16 = m16.generate(input_ids=torch.from_numpy(ids[:3]), attention_mask=torch.from_numpy(mask[:3]))
+    assert o16.shape[0] == 3 and o16.shape[1] >= T - 7 + 7
+    assert torch.equal(o16[:, :T - 7], torch.from_numpy(ids[:3, :T - 7]))
     with pytest.raises(NotImplementedError):
-        AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.float16)
+        AsteroidTTSInstruct.from_pretrained(str(d), torch_dtype=torch.float64)
 
 
 def test_config5_voice_clone_long_context_end_to_end():
