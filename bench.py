@@ -415,34 +415,58 @@ def main():
     # N>1 (BASELINE configs[3]: "RCCL broadcast weights, gather audio"): every rank decodes the frames it generated and
     # rank 0 receives all the audio (mtts.dist.gather_audio: one exact-size buffer per rank over its own xGMI link)
     e2e_sharded = None
+    e2e_hung = False
     if world > 1 and not args.no_codec and not args.fake_context:
-        from mtts import dist as mdist
-        wavs = []
-        leg = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all, keep=wavs)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        # (gloo rehearsals on a 1-GPU box exchange through host memory: gloo has no device send / recv)
-        got = mdist.gather_audio([(rank * B + i, w) for i, w in enumerate(wavs)], device if backend == "nccl" else torch.device("cpu"))
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_gather = time.perf_counter() - t0
-        tm = torch.tensor([leg["prefill_s"], leg["decode_s"], leg["codec_s"], t_gather], dtype=torch.float64, device=device)
-        sm = torch.tensor([leg["audio_seconds"], float(leg["frames"])], dtype=torch.float64, device=device)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            assert len(got) == world * B and all(w is not None for _, w in got)
-            gathered = sum(int(w.numel()) for _, w in got)
-            assert abs(gathered / 24000.0 - float(sm[0])) < 1e-3 * float(sm[0])
-            wall = float(tm.sum())
-            e2e_sharded = {"prefill_s": float(tm[0]), "decode_s": float(tm[1]), "codec_s": float(tm[2]), "gather_s": float(tm[3]),
-                           "gathered_bytes": gathered * 4, "gather_GBps_into_rank0": gathered * 4 / max(float(tm[3]), 1e-9) / 1e9,
-                           "frames": int(sm[1]), "audio_seconds": float(sm[0]), "codec_ids_per_s": float(sm[1]) * 8 / wall,
-                           "real_time_factor": float(sm[0]) / wall,
-                           "note": "slowest rank's prefill + decode (context ramp + timed steps) + codec decode of all its frames, "
-                                   "then the audio of every rank gathered on rank 0"}
-        del wavs, got
+        # The leg runs on a helper thread with a deadline: the headline line must be printed even if the codec or the
+        # audio exchange (RCCL point-to-point, never run on hardware before the first 8-GPU bench) gets stuck.
+        import threading
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(device)
+                from mtts import dist as mdist
+                wavs = []
+                r = end_to_end_leg(eng, device, B, T, t_prefill, t_decode_all, steps_all, keep=wavs)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                # (gloo rehearsals on a 1-GPU box exchange through host memory: gloo has no device send / recv)
+                got = mdist.gather_audio([(rank * B + i, w) for i, w in enumerate(wavs)],
+                                         device if backend == "nccl" else torch.device("cpu"))
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_gather = time.perf_counter() - t0
+                tm = torch.tensor([r["prefill_s"], r["decode_s"], r["codec_s"], t_gather], dtype=torch.float64, device=device)
+                sm = torch.tensor([r["audio_seconds"], float(r["frames"])], dtype=torch.float64, device=device)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    assert len(got) == world * B and all(w is not None for _, w in got)
+                    gathered = sum(int(w.numel()) for _, w in got)
+                    assert abs(gathered / 24000.0 - float(sm[0])) < 1e-3 * float(sm[0])
+                    wall = float(tm.sum())
+                    box["out"] = {"prefill_s": float(tm[0]), "decode_s": float(tm[1]), "codec_s": float(tm[2]), "gather_s": float(tm[3]),
+                                  "gathered_bytes": gathered * 4, "gather_GBps_into_rank0": gathered * 4 / max(float(tm[3]), 1e-9) / 1e9,
+                                  "frames": int(sm[1]), "audio_seconds": float(sm[0]), "codec_ids_per_s": float(sm[1]) * 8 / wall,
+                                  "real_time_factor": float(sm[0]) / wall,
+                                  "note": "slowest rank's prefill + decode (context ramp + timed steps) + codec decode of all its frames, "
+                                          "then the audio of every rank gathered on rank 0"}
+                box["done"] = True
+            except Exception as ex:          # noqa: BLE001
+                box["err"] = repr(ex)
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("MTTS_BENCH_E2E_DEADLINE", "240")))
+        if th.is_alive():
+            e2e_hung = True
+            e2e_sharded = {"error": "the sharded end-to-end leg (codec decode + audio gather) did not finish before its deadline; "
+                                    "the headline figures above do not depend on it"}
+        elif "err" in box:
+            e2e_sharded = {"error": box["err"]}
+        else:
+            e2e_sharded = box.get("out")
 
     if rank == 0:
         Lt = L - args.profile_steps - K // 2          # mean KV length inside the timed region
@@ -542,6 +566,8 @@ def main():
             except Exception:
                 pass
         print(json.dumps(out), flush=True)
+    if e2e_hung:
+        os._exit(0)            # a stuck exchange must not keep the job (and the line already printed) hostage
     eng.close()
     if world > 1:
         dist.destroy_process_group()

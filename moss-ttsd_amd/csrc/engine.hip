@@ -75,7 +75,7 @@ void launch_f32_embed_norm(const int32_t* tokens, const RowMeta* meta, const flo
                            float* xn, int R, int H, float eps, int h16, hipStream_t st);
 void launch_f32_resid_norm(const float* y, float* x, const float* norm_w, float* xn, float* hlast, const RowMeta* meta, int R,
                            int H, float eps, int h16, hipStream_t st);
-void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, int h16, hipStream_t st);
+void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, int h16, bool gemv, hipStream_t st);
 void launch_f32_qkv_post(const float* qkv, int ldq, const RowMeta* meta, const float* qnw, const float* knw, const float* cosb,
                          const float* sinb, float* qbuf, float* kcache, float* vcache, const int32_t* page_table, int max_pages,
                          int total_pages, int R, int nq, int nkv, float eps, int h16, hipStream_t st);
@@ -337,21 +337,22 @@ static int forward_rows_f32(MttsEngine* e, const int32_t* d_tokens, const RowMet
     const int H = e->H, I = e->I, nq = e->nq, nkv = e->nkv;
     const float eps = e->cfg.rms_norm_eps, scale = 1.0f / sqrtf((float)MTTS_HD);
     const int Lmax = e->max_pages * MTTS_PAGE, h16 = e->h16;
+    const bool dec = heads == 1;                       // decode rows: GEMV in groups of 8 (batch-independent numerics)
     launch_f32_embed_norm(d_tokens, d_meta, e->d_tables_f, e->lf[0].ln_in, e->xf, e->xnf, R, H, eps, h16, st);
     for (int n = 0; n < e->L; ++n) {
         auto& l = e->lf[n];
         float* kc = e->kcache_f + e->layer_stride * n;
         float* vc = e->vcache_f + e->layer_stride * n;
-        launch_f32_linear(l.wqkv, e->xnf, e->qkvf, R, e->qkv_rows, H, e->qkv_rows, h16, st);
+        launch_f32_linear(l.wqkv, e->xnf, e->qkvf, R, e->qkv_rows, H, e->qkv_rows, h16, dec, st);
         launch_f32_qkv_post(e->qkvf, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos_f, e->rope_sin_f, e->qbuf_f, kc, vc,
                             e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, h16, st);
         launch_f32_attn(e->qbuf_f, kc, vc, e->d_page_table, d_meta, e->scores_f, e->attnf, R, e->max_pages, e->total_pages, nq,
                         nkv, scale, Lmax, h16, st);
-        launch_f32_linear(l.wo, e->attnf, e->yf, R, H, nq * MTTS_HD, H, h16, st);
+        launch_f32_linear(l.wo, e->attnf, e->yf, R, H, nq * MTTS_HD, H, h16, dec, st);
         launch_f32_resid_norm(e->yf, e->xf, l.ln_post, e->xnf, nullptr, d_meta, R, H, eps, h16, st);
-        launch_f32_linear(l.wgu, e->xnf, e->guf, R, 2 * I, H, 2 * I, h16, st);
+        launch_f32_linear(l.wgu, e->xnf, e->guf, R, 2 * I, H, 2 * I, h16, dec, st);
         launch_f32_swiglu(e->guf, e->actf, R, I, h16, st);
-        launch_f32_linear(l.wd, e->actf, e->yf, R, H, I, H, h16, st);
+        launch_f32_linear(l.wd, e->actf, e->yf, R, H, I, H, h16, dec, st);
         const bool lastl = n == e->L - 1;
         launch_f32_resid_norm(e->yf, e->xf, lastl ? e->final_norm_f : e->lf[n + 1].ln_in, e->xnf, lastl ? e->hlast_f : nullptr,
                               d_meta, R, H, eps, h16, st);
@@ -359,9 +360,9 @@ static int forward_rows_f32(MttsEngine* e, const int32_t* d_tokens, const RowMet
     if (heads) {
         // decode rows are the dialogues themselves (row b = slot b); after a prefill the last tokens' states are in hlast
         const float* xin = heads == 1 ? e->xnf : e->hlast_f;
-        launch_f32_linear(e->embf[0], xin, (float*)e->logits0, e->B, e->V0, H, e->V0_pad, h16, st);
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0, e->B, e->V0, H, e->V0_pad, h16, true, st);
         for (int c = 1; c < 8; ++c)
-            launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)(c - 1) * e->Vs_pad, e->B, e->Vs, H, 7 * e->Vs_pad, h16, st);
+            launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)(c - 1) * e->Vs_pad, e->B, e->Vs, H, 7 * e->Vs_pad, h16, true, st);
     }
     HIPCHK(hipGetLastError());
     return MTTS_OK;
@@ -1299,10 +1300,10 @@ int32_t mtts_slot_submit_row(MttsEngine* e, int32_t slot, const int64_t* ids, in
     // (the other slots' logits belong to dialogues that are mid-flight)
     if (e->f32) {            // fp32 engine: the GEMV writes the slot's logits rows directly
         const float* xin = e->hlast_f + (size_t)slot * e->H;
-        launch_f32_linear(e->embf[0], xin, (float*)e->logits0 + (size_t)slot * e->V0_pad, 1, e->V0, e->H, e->V0_pad, e->h16, st);
+        launch_f32_linear(e->embf[0], xin, (float*)e->logits0 + (size_t)slot * e->V0_pad, 1, e->V0, e->H, e->V0_pad, e->h16, true, st);
         for (int c = 1; c < 8; ++c)
             launch_f32_linear(e->embf[c], xin, (float*)e->logits17 + (size_t)slot * 7 * e->Vs_pad + (size_t)(c - 1) * e->Vs_pad, 1, e->Vs,
-                              e->H, 7 * e->Vs_pad, e->h16, st);
+                              e->H, 7 * e->Vs_pad, e->h16, true, st);
     } else {
     HIPCHK(hipMemsetAsync(e->xh, 0, (size_t)MTTS_MAXR * e->H * 2, st));
     launch_pack_rows((const uint16_t*)e->hlast + (size_t)slot * e->H, e->xh, 1, e->H, 1, st);

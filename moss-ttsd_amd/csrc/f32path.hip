@@ -17,6 +17,8 @@
 // (r16 below; the same points at which the bf16 kernels round to bf16).  Accumulations stay fp32, as torch's do.
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 __device__ __forceinline__ float r16(float v, int h16) { return h16 ? __half2float(__float2half_rn(v)) : v; }
@@ -224,10 +226,14 @@ void launch_f32_resid_norm(const float* y, float* x, const float* norm_w, float*
     hipLaunchKernelGGL(f32_resid_norm_kernel, dim3(R), dim3(256), 0, st, y, x, norm_w, xn, hlast, meta, H, eps, h16);
 }
 void mtts_gemm_f32_exact(hipStream_t st, const float* A, const float* W, float* C, int M, int N, int K, long ldc);   // codec.hip
-// rows are processed 8 at a time by the GEMV; bigger passes (prefill) take the exact-f32 MFMA GEMM
-void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, int h16, hipStream_t st) {
-    if (R <= 8) {
-        hipLaunchKernelGGL(f32_gemv_kernel, dim3((N + 4 * F32_CPW - 1) / (4 * F32_CPW)), dim3(256), 0, st, W, X, Y, R, N, K, ldy, h16);
+// Decode rows (one dialogue each; `gemv`) go through the GEMV kernel 8 rows per launch whatever the batch size, prefill
+// passes through the exact-f32 MFMA GEMM whatever their row count: which kernel -- hence which fp32 summation order -- a
+// dialogue's numbers come from must not depend on how many other dialogues share its batch.
+void launch_f32_linear(const float* W, const float* X, float* Y, int R, int N, int K, long ldy, int h16, bool gemv, hipStream_t st) {
+    if (gemv) {
+        for (int r0 = 0; r0 < R; r0 += 8)
+            hipLaunchKernelGGL(f32_gemv_kernel, dim3((N + 4 * F32_CPW - 1) / (4 * F32_CPW)), dim3(256), 0, st, W, X + (size_t)r0 * K,
+                               Y + (size_t)r0 * ldy, std::min(8, R - r0), N, K, ldy, h16);
         return;
     }
     mtts_gemm_f32_exact(st, X, W, Y, R, N, K, ldy);

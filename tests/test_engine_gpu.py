@@ -802,3 +802,30 @@ def test_fp16_engine_parity_with_reference_fixture(golden_dir):
             break
     eng.close()
     assert exact >= 0.3 * total, (exact, total)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_fp32_family_engines_are_batch_invariant(dtype):
+    """The fp32 / fp16 engines take the GEMV kernel for decode rows (8 rows per launch, whatever the batch) and the MFMA
+    GEMM for prefill passes (whatever their row count), so a dialogue's fp32 summation order -- and with it every
+    low-margin pick -- does not depend on how many dialogues share its batch: 12 ragged dialogues in one static batch
+    equal their batch-1 runs, greedy and sampled (per-row Philox streams)."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 271, bf16=False, emb_row_sigma=0.6, speech_boost=6.0, eos_boost=1.0)
+    ids, mask = synth.synth_prompts(cfg, 272, 12, 40, 0.4, True)
+    T = ids.shape[1]
+    max_length = T + 30
+    layers = [dict(top_k=20, top_p=0.9, temperature=1.1)] * 8
+    eng = Engine(cfg, max_batch=16, max_seq_len=256, dtype=dtype)
+    eng.bind_state_dict(w)
+    full = eng.generate(ids, mask, max_length)
+    samp = eng.generate(ids, mask, max_length, layers=layers, do_samples=[True] * 8, seed=13)
+    for b in (0, 5, 11):
+        pad = int(np.argmax(mask[b] > 0))
+        p = ids[b, pad:][None]
+        one = eng.generate(p, np.ones((1, p.shape[1])), p.shape[1] + 30)
+        assert np.array_equal(one[0, p.shape[1] - 7:], full[b, T - 7:T - 7 + one.shape[1] - (p.shape[1] - 7)]), b
+        one_s = eng.generate(p, np.ones((1, p.shape[1])), p.shape[1] + 30, layers=layers, do_samples=[True] * 8, seed=13, row_ids=[b])
+        assert np.array_equal(one_s[0, p.shape[1] - 7:], samp[b, T - 7:T - 7 + one_s.shape[1] - (p.shape[1] - 7)]), b
+    eng.close()
