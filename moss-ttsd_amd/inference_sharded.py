@@ -48,6 +48,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available()
+    if cuda and backend not in (None, "nccl"):
+        local %= max(torch.cuda.device_count(), 1)       # gloo rehearsals: several ranks may share one card
     device = torch.device(f"cuda:{local}") if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(device)

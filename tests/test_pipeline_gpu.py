@@ -357,3 +357,78 @@ def test_finetune_data_path_through_the_hip_encoder(tmp_path):
             assert np.array_equal(labels[a0:a0 + n_audio], ids[a0:a0 + n_audio]) and (labels[:a0] == -100).all()
             assert np.array_equal(labels[a0 + n_audio:, 0], ids[a0 + n_audio:, 0])
     assert list(metas[2]) == [37, 25 + 50]
+
+
+def _two_rank_worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        for pth in (os.path.dirname(here), os.path.join(os.path.dirname(here), "moss-ttsd_amd"), here):
+            if pth not in sys.path:
+                sys.path.insert(0, pth)
+        import torch.distributed as dist
+        import inference_sharded as ish
+        world, r, dev = ish.init_distributed(backend="gloo")
+        torch.manual_seed(123)
+        tok, model, spt = ish.load_model_sharded("m", "c", "k", device=dev, loader=_tiny_loader)
+        texts, audio = ish.process_batch_sharded(_SHARD_ITEMS, tok, model, spt, str(dev), "sys", 10)
+        if r == 0:
+            q.put(("ok", texts, [None if a is None else a["audio_data"].numpy() for a in audio]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", repr(e) + traceback.format_exc(), None))
+
+
+_SHARD_ITEMS = [{"text": "[S1]" + "word " * (3 + 5 * (i % 4)) + "[S2]ok."} for i in range(7)]
+
+
+def _tiny_loader(model_path, spt_cfg, spt_ckpt, torch_dtype=None, attn_implementation=None):
+    from modeling_asteroid import AsteroidTTSInstruct, GenerationConfig
+    from XY_Tokenizer.xy_tokenizer.model import XY_Tokenizer
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 321, emb_row_sigma=0.6, speech_boost=5.0, eos_boost=4.0)
+    layers = [dict(top_k=20, top_p=0.9, temperature=1.05, repetition_penalty=1.1)] * 8
+    gc = GenerationConfig(max_new_tokens=26, do_samples=[True] * 8, layers=layers, eos_token_id=cfg["eos_token_id"])
+    model = AsteroidTTSInstruct.from_state_dict(cfg, {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in w.items()}, gc)
+    ccfg = synth_codec.reduced(dec_layers=1, voc_layers=1)
+    spt = XY_Tokenizer(_gp(ccfg), {k: torch.from_numpy(v) for k, v in synth_codec.synth_weights(ccfg, 9).items()})
+    return Tok(), model.eval(), spt.eval()
+
+
+def test_sharded_two_ranks_equal_the_single_process_run():
+    """BASELINE configs[3]'s flow on hardware, minus RCCL: two ranks (gloo; both on this box's one GPU) run
+    inference_sharded -- rank 0 alone builds the models, weights travel as flat buckets, the 7 items are dealt by
+    estimated work, each rank runs process_batch on its share with its rows' job-wide Philox ids, audio and text records
+    meet on rank 0.  SAMPLED on all 8 channels: the result must equal one process_batch over the whole batch in this
+    process (same seed), token for token and therefore sample for sample."""
+    import socket
+    import torch.multiprocessing as mp
+    import generation_utils as gu
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, texts, audio = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", texts
+    torch.manual_seed(123)
+    tok, model, spt = _tiny_loader("m", "c", "k")
+    want_t, want_a = gu.process_batch(_SHARD_ITEMS, tok, model.to("cuda"), spt.to("cuda"), "cuda", "sys", 10)
+    assert texts == want_t
+    assert len(audio) == len(want_a) == 7
+    for got, ref in zip(audio, want_a):
+        assert (got is None) == (ref is None)
+        if ref is not None:
+            assert got.shape == tuple(ref["audio_data"].shape)
+            assert np.array_equal(got, ref["audio_data"].numpy())
+    assert not np.array_equal(audio[0], audio[1])          # (different dialogues, different draws)
