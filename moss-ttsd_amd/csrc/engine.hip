@@ -1442,6 +1442,17 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 }
 
 // ---- per-kernel entry points --------------------------------------------------------
+// device buffers of a test hook: freed on every return path
+struct HookBufs {
+    std::vector<void*> p;
+    ~HookBufs() { for (void* q : p) if (q) hipFree(q); }
+    template <typename T>
+    int get(T** out, size_t n, bool zero = true) {
+        int rc = dalloc(out, n, zero);
+        if (!rc) p.push_back((void*)*out);
+        return rc;
+    }
+};
 int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* stream) {
     if (!w || !x || !y || M < 1 || M > MTTS_PFCAP || K % 16 || N < 1) return fail(MTTS_EINVAL, "gemm: need 1<=M<=MTTS_PFCAP, K%%16==0");
     hipStream_t st = S(stream);
@@ -1449,12 +1460,13 @@ int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32
     void *wp = nullptr, *xp = nullptr;
     float* part = nullptr;
     GemmPlan p = mtts_plan_gemm(Npad, K, ksplit);
-    TRY(dalloc((uint16_t**)&wp, (size_t)Npad * K));
+    HookBufs hb;
+    TRY(hb.get((uint16_t**)&wp, (size_t)Npad * K));
     // M <= 128: skinny kernel (decode); above: tiled kernel (prefill), ksplit as given or its own choice
     const bool tiled = M > MTTS_RCAP;
     const int ks = tiled ? (ksplit > 0 ? ksplit : mtts_tile_ksplit(Npad, K, M)) : p.ksplit;
-    TRY(dalloc((uint16_t**)&xp, (size_t)MTTS_PFCAP * K));
-    TRY(dalloc(&part, (size_t)ks * MTTS_PFCAP * Npad));
+    TRY(hb.get((uint16_t**)&xp, (size_t)MTTS_PFCAP * K));
+    TRY(hb.get(&part, (size_t)ks * MTTS_PFCAP * Npad));
     launch_pack_weight(w, wp, N, K, Npad, 1, 0, st);
     const int tiles = (M + 31) / 32;
     launch_pack_rows(x, xp, M, K, tiles == 3 ? 4 : tiles, st);
@@ -1463,7 +1475,6 @@ int32_t mtts_k_gemm_bf16(const void* w, const void* x, void* y, int32_t M, int32
     launch_reduce_partial_bf16(part, y, ks, Npad, N, M, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(wp); hipFree(xp); hipFree(part);
     return MTTS_OK;
 }
 
@@ -1482,17 +1493,19 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     for (int i = 0; i < 8; ++i) h[i] = *cfg;
     MttsSamplerCfg* d = nullptr;
     int32_t *err = nullptr, *dec = nullptr;
-    TRY(dalloc(&d, 8));
-    TRY(dalloc(&err, 1));
-    TRY(dalloc(&dec, (size_t)rows * 8));
-    HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
     if (rows > MTTS_RCAP) return fail(MTTS_EINVAL, "sample: at most 128 rows");
+    HookBufs hb;
+    TRY(hb.get(&d, 8));
+    TRY(hb.get(&err, 1));
+    TRY(hb.get(&dec, (size_t)rows * 8));
+    HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
     SampleScratch sc;
+    struct ScratchGuard { SampleScratch* s; ~ScratchGuard() { free_scratch(*s); } } sg{&sc};
+    sc = SampleScratch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     TRY(alloc_scratch(sc, rows, vocab));
     launch_sample_single(logits, rows, vocab, (const uint32_t*)bitmap, (vocab + 31) / 32, d, mask_id, seed, step, channel, dec, err, sc, full_cap_for(vocab), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    free_scratch(sc);
     std::vector<int32_t> hd((size_t)rows * 8);
     int32_t herr = 0;
     HIPCHK(hipMemcpy(hd.data(), dec, hd.size() * 4, hipMemcpyDeviceToHost));
@@ -1500,7 +1513,6 @@ int32_t mtts_k_sample(const void* logits, int32_t rows, int32_t vocab, const voi
     std::vector<int32_t> outv(rows);
     for (int r = 0; r < rows; ++r) outv[r] = hd[(size_t)r * 8 + channel];
     HIPCHK(hipMemcpy(dev_tokens, outv.data(), rows * 4, hipMemcpyHostToDevice));
-    hipFree(d); hipFree(err); hipFree(dec);
     if (herr) return fail(MTTS_EINVAL, "sample: more than 4096 candidate tokens");
     return MTTS_OK;
 }
@@ -1525,9 +1537,10 @@ int32_t mtts_k_rope_kvwrite(const void* dev_qkv, const int32_t* host_pos, const 
     for (int r = 0; r < R; ++r) { if (host_pos[r] < 0) return fail(MTTS_EINVAL, "negative position"); maxpos = std::max(maxpos, host_pos[r]); }
     const int max_pages = maxpos / MTTS_PAGE + 1, total_pages = R * max_pages;
     float* slab = nullptr; RowMeta* meta = nullptr; int32_t* pt = nullptr; uint16_t *kc = nullptr, *vc = nullptr;
-    TRY(dalloc(&slab, (size_t)MTTS_PFCAP * N));
-    TRY(dalloc(&meta, R)); TRY(dalloc(&pt, (size_t)R * max_pages));
-    TRY(dalloc(&kc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD)); TRY(dalloc(&vc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD));
+    HookBufs hb;
+    TRY(hb.get(&slab, (size_t)MTTS_PFCAP * N));
+    TRY(hb.get(&meta, R)); TRY(hb.get(&pt, (size_t)R * max_pages));
+    TRY(hb.get(&kc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD)); TRY(hb.get(&vc, (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD));
     std::vector<RowMeta> hm(R);
     std::vector<int32_t> hpt((size_t)R * max_pages);
     for (int r = 0; r < R; ++r) { hm[r] = RowMeta{r, host_pos[r], 1, 0}; for (int p = 0; p < max_pages; ++p) hpt[(size_t)r * max_pages + p] = r * max_pages + p; }
@@ -1551,7 +1564,6 @@ int32_t mtts_k_rope_kvwrite(const void* dev_qkv, const int32_t* host_pos, const 
             }
     HIPCHK(hipMemcpy(dev_k, ok.data(), ok.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dev_v, ov.data(), ov.size() * 2, hipMemcpyHostToDevice));
-    hipFree(slab); hipFree(meta); hipFree(pt); hipFree(kc); hipFree(vc);
     return MTTS_OK;
 }
 
@@ -1583,12 +1595,13 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
     RowMeta* meta = nullptr; int32_t *pt = nullptr, *lens = nullptr; uint16_t *kc = nullptr, *vc = nullptr, *scores = nullptr, *outp = nullptr;
     float *stats = nullptr, *opart = nullptr;
     const size_t cache_n = (size_t)total_pages * nkv * MTTS_PAGE * MTTS_HD;
-    TRY(dalloc(&meta, MTTS_MAXR)); TRY(dalloc(&pt, hpt.size())); TRY(dalloc(&lens, R));
-    TRY(dalloc(&kc, cache_n)); TRY(dalloc(&vc, cache_n));
-    TRY(dalloc(&scores, (size_t)MTTS_MAXR * nq * max_pages * MTTS_PAGE));
-    TRY(dalloc(&stats, (size_t)MTTS_MAXR * nq * max_pages * 2));
-    TRY(dalloc(&opart, (size_t)MTTS_MAXR * nq * nch * MTTS_HD));
-    TRY(dalloc(&outp, (size_t)MTTS_MAXR * nq * MTTS_HD));
+    HookBufs hb;
+    TRY(hb.get(&meta, MTTS_MAXR)); TRY(hb.get(&pt, hpt.size())); TRY(hb.get(&lens, R));
+    TRY(hb.get(&kc, cache_n)); TRY(hb.get(&vc, cache_n));
+    TRY(hb.get(&scores, (size_t)MTTS_MAXR * nq * max_pages * MTTS_PAGE));
+    TRY(hb.get(&stats, (size_t)MTTS_MAXR * nq * max_pages * 2));
+    TRY(hb.get(&opart, (size_t)MTTS_MAXR * nq * nch * MTTS_HD));
+    TRY(hb.get(&outp, (size_t)MTTS_MAXR * nq * MTTS_HD));
     HIPCHK(hipMemcpy(meta, hm.data(), hm.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pt, hpt.data(), hpt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(lens, host_lens, R * 4, hipMemcpyHostToDevice));
@@ -1600,7 +1613,6 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
     launch_unpack_rows(outp, dev_out, R, nq * MTTS_HD, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(meta); hipFree(pt); hipFree(lens); hipFree(kc); hipFree(vc); hipFree(scores); hipFree(stats); hipFree(opart); hipFree(outp);
     return MTTS_OK;
 }
 

@@ -72,7 +72,7 @@ def test_oracle_replay_matches_reference(golden_dir, name):
 def test_oracle_free_run_matches_reference_prefix(golden_dir):
     """Free-running greedy ids equal the reference's up to the first low-margin decision."""
     compared = 0
-    for name in CASES:
+    for name in CASES[:-1]:              # (ar_wide: a minute of numpy per run; the replay test above covers it)
         z, cfg, w = load_case(golden_dir, name)
         orc = ao.AsteroidOracle(cfg, w, "bf16")
         layers = json.loads(str(z["layers"])) or None
