@@ -1045,7 +1045,14 @@ struct MttsCodec {
     int nt_out = 1;             // nontemporal stores of the GELU GEMMs' output planes (393 MB per Vocos pw1 launch: -1.3 % per window; MTTS_CODEC_NT_OUT=0: off)
     int dw_rows = 4;            // dwconv_ln512_kernel: rows per wave (4: 31 us per launch at 8 windows; 8: 46 us, 2: 33 us)
     int tile = 0;               // gemm_b3t_kernel: MTTS_CODEC_TILE = NA NB U OCC as digits forces one variant (0: per shape)
+    // Vocos pw1 -> GELU -> pw2 in one launch (codec_fused.hip): -1 = where it pays (fused_pw_pays), 0 = never, N = from N rows
+    // per call up (MTTS_CODEC_FUSED_PW)
+    long fused_pw_rows = -1;
+    std::map<const float*, uint16_t*> wplanes_perm;   // W2 planes with the K order the fused kernel's second GEMM expects
 };
+void launch_split_pack_w2perm(hipStream_t st, const float* w2, uint16_t* hi, uint16_t* lo);
+void launch_vocos_pw_fused(hipStream_t st, const uint16_t* xn_planes, long x_plane_elems, const uint16_t* w1_planes, const float* b1,
+                           const uint16_t* w2perm_planes, long w_plane_elems, const float* b2, const float* gamma, float* h, int M);
 
 extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, MttsCodec** out) {
     if (!c || !out) return cfail(MTTS_EINVAL, "null argument");
@@ -1063,6 +1070,7 @@ extern "C" int32_t mtts_codec_create(const MttsCodecConfig* c, int32_t device, M
     if (const char* m = getenv("MTTS_CODEC_DW_ROWS")) k->dw_rows = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_NT_OUT")) k->nt_out = atoi(m);
     if (const char* m = getenv("MTTS_CODEC_ATTN_PACKED")) k->attn_packed = atoi(m);
+    if (const char* m = getenv("MTTS_CODEC_FUSED_PW")) k->fused_pw_rows = atol(m);
     if (const char* m = getenv("MTTS_CODEC_XCD")) { const int v = atoi(m) != 0; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_map), &v, sizeof(int))); }
     CHK(hipMalloc((void**)&k->d_err, 4));
     CHK(hipMemset(k->d_err, 0, 4));
@@ -1076,6 +1084,7 @@ extern "C" int32_t mtts_codec_destroy(MttsCodec* k) {
     hipDeviceSynchronize();
     for (auto& kv : k->w) hipFree(kv.second);
     for (auto& kv : k->wplanes) hipFree(kv.second);
+    for (auto& kv : k->wplanes_perm) hipFree(kv.second);
     float* bufs[] = {k->bufA, k->bufB, k->bufC, k->bufD, k->bufE, k->big, k->scores, k->melbuf, k->melmax};
     for (float* p : bufs) if (p) hipFree(p);
     if (k->d_lens2) hipFree(k->d_lens2);
@@ -1097,6 +1106,8 @@ extern "C" int32_t mtts_codec_bind(MttsCodec* k, const char* role, const float* 
     if (k->w.count(r)) {
         auto pl = k->wplanes.find(k->w[r]);
         if (pl != k->wplanes.end()) { CHK(hipDeviceSynchronize()); hipFree(pl->second); k->wplanes.erase(pl); }
+        auto pp = k->wplanes_perm.find(k->w[r]);
+        if (pp != k->wplanes_perm.end()) { CHK(hipDeviceSynchronize()); hipFree(pp->second); k->wplanes_perm.erase(pp); }
         hipFree(k->w[r]); k->w.erase(r);
     }
     float* p = nullptr;
@@ -1179,6 +1190,43 @@ static int b3t_launch(hipStream_t st, const GemmF32Args& g, int code) {
 // gamma / residual as gemm_f32) or, with c_planes, fragment-packed planes in the same buffer (the next GEMM's A).
 static bool planes_ok(const MttsCodec* k, int K, long lda) { return k->planes && g_gemm_split && K % 64 == 0 && lda == K; }
 static inline long pad32(long r) { return (r + 31) / 32 * 32; }
+// bf16 hi / lo planes of a constant weight [N][K], fragment-packed (made on first use; hi plane, lo plane pad32(N) * K further)
+static int weight_planes(MttsCodec* k, hipStream_t st, const float* W, int N, int K, uint16_t** out) {
+    auto it = k->wplanes.find(W);
+    if (it != k->wplanes.end()) { *out = it->second; return 0; }
+    uint16_t* wp = nullptr;
+    const long wn = pad32(N) * (long)K;
+    CHK(hipMalloc((void**)&wp, (size_t)wn * 4));
+    CHK(hipMemsetAsync(wp, 0, (size_t)wn * 4, st));
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(split_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, wp, wp + wn, N, K);
+    CHK(hipStreamSynchronize(st));           // once per weight: later calls may come in on another stream
+    k->wplanes[W] = wp;
+    *out = wp;
+    return 0;
+}
+// the fused Vocos kernel's second weight: planes with its permuted K order (codec_fused.hip)
+static int weight_planes_perm(MttsCodec* k, hipStream_t st, const float* W2, long elems, uint16_t** out) {
+    auto it = k->wplanes_perm.find(W2);
+    if (it != k->wplanes_perm.end()) { *out = it->second; return 0; }
+    uint16_t* wp = nullptr;
+    CHK(hipMalloc((void**)&wp, (size_t)elems * 4));
+    launch_split_pack_w2perm(st, W2, wp, wp + elems);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(st));
+    k->wplanes_perm[W2] = wp;
+    *out = wp;
+    return 0;
+}
+// The fused kernel runs ONE 64-row block per CU at a time (it owns all 160 KiB of LDS), so a call takes
+// ceil(blocks / 256) rounds of ~340 us whatever the last round holds: it beats the two launches (0.0253 us per row) when
+// the last round is nearly full, and from 12 windows per call up in any case (measured 4 .. 32 windows per call,
+// profiles/r03_codec_fused_pw.json: -8 % per window at 16 and 32, +4 % at 8).
+static bool fused_pw_pays(long rows, long setting) {
+    if (setting >= 0) return setting > 0 && rows >= setting;
+    const long blocks = (rows + 63) / 64, rounds = (blocks + 255) / 256;
+    return rows >= 36000 || (double)blocks / (double)(rounds * 256) >= 0.90;
+}
 static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long a_rows, const float* W, float* C, int M, int N,
                        int K, long lda, long ldc, const float* bias, int act, const float* gamma, const float* res, long ldres,
                        bool c_planes, long c_rows) {
@@ -1188,15 +1236,7 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
     if (combo != 0 && combo != 4 && combo != 6 && combo != 9) return cfail(MTTS_EINVAL, "gemm_planes: no epilogue for flag combination %d", combo);
     uint16_t* wp = nullptr;
     const long wn = pad32(N) * (long)K;                      // elements per weight plane
-    auto it = k->wplanes.find(W);
-    if (it == k->wplanes.end()) {
-        CHK(hipMalloc((void**)&wp, (size_t)wn * 4));
-        CHK(hipMemsetAsync(wp, 0, (size_t)wn * 4, st));
-        const long n = (long)N * K;
-        hipLaunchKernelGGL(split_pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, wp, wp + wn, N, K);
-        CHK(hipStreamSynchronize(st));           // once per weight: later calls may come in on another stream
-        k->wplanes[W] = wp;
-    } else wp = it->second;
+    TRYC(weight_planes(k, st, W, N, K, &wp));
     // activation planes: hi plane first, lo plane pad32(M) rows further (both in fragment order, K = row length)
     GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
                   (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
@@ -1802,6 +1842,14 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
             else
                 hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
                                    vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
+            if (vd == 512 && vi == 4096 && fused_pw_pays(rows8, k->fused_pw_rows)) {
+                // pw1 -> GELU -> pw2 in one launch: the 4096-wide intermediate stays on the CU
+                uint16_t *w1p = nullptr, *w2p = nullptr;
+                TRYC(weight_planes(k, st, p1_w, vi, vd, &w1p));
+                TRYC(weight_planes_perm(k, st, p2_w, (long)vd * vi, &w2p));
+                launch_vocos_pw_fused(st, (const uint16_t*)Cc, pad32(rows8) * (long)vd, w1p, p1_b, w2p, (long)vd * vi, p2_b, gam, A, rows8);
+                continue;
+            }
             TRYC(gemm_planes(k, st, Cc, rows8, p1_w, k->big, rows8, vi, vd, vd, vi, p1_b, 1, nullptr, nullptr, 0, true, rows8));
             TRYC(gemm_planes(k, st, k->big, rows8, p2_w, A, rows8, vd, vi, vi, vd, p2_b, 0, gam, A, vd, false, 0));   // h += gamma * pw2(..)
             continue;

@@ -193,6 +193,35 @@ def test_codec_full_depth_full_window_vs_reference(golden_dir, monkeypatch, name
     _dump(f"r03_codec_full_{name}_{mode}.json", rec)
 
 
+@pytest.mark.parametrize("name", ["codec_full_T375", "codec_full_T520"])
+def test_codec_fused_pointwise_kernel_vs_reference_and_two_launch_form(golden_dir, monkeypatch, name):
+    """The Vocos pw1 -> GELU -> pw2 kernel (csrc/codec_fused.hip; the engine picks it by itself only for large calls,
+    here it is forced from the first row) on the same full-depth fixtures: within the 1e-4 tolerance of the reference's
+    waveform, and within 1e-5 RMS of the two-launch form (both are bf16x3 GEMMs; the second GEMM's K order differs).
+    3 000 and 3 x 3 000 rows: the last 64-row block is ragged in both."""
+    from mtts.codec import CodecEngine
+    z, cfg = _codec_case(golden_dir, name)
+    w = synth_codec.synth_weights(cfg, int(z["seed"]))
+    codes = synth_codec.synth_codes(cfg, int(z["seed"]) + 1, list(z["lengths"]))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MTTS_CODEC_FUSED_PW", mode)
+        eng = CodecEngine(cfg)
+        eng.bind_state_dict(w)
+        out[mode] = [x.cpu().numpy().astype(np.float64) for x in eng.decode([torch.from_numpy(c) for c in codes])]
+        eng.close()
+    stride = int(z["stride"])
+    rec = {}
+    for i, (a, b) in enumerate(zip(out["0"], out["1"])):
+        ref = z[f"wav{i}_sub"].astype(np.float64)
+        err = float(np.sqrt(np.mean((b[::stride] - ref) ** 2)))
+        dif = float(np.sqrt(np.mean((a - b) ** 2)))
+        rec[f"wav{i}"] = {"rms_error_fused": err, "rms_fused_vs_two_launch": dif}
+        assert err <= 1e-4, (name, err)
+        assert 0.0 < dif <= 1e-5, (name, dif)       # > 0: the fused kernel really ran
+    _dump(f"r03_codec_fused_{name}.json", rec)
+
+
 @pytest.mark.parametrize("name", ["codec_enc_full_12s", "codec_enc_full_ragged"])
 def test_encoder_full_depth_exact_ids(golden_dir, name):
     """The two 12-layer OmniAudioEncoders + the 4-layer adapters + down-conv + 8-stage RVQ search against the
