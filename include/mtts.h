@@ -182,6 +182,12 @@ int32_t mtts_profile_read(MttsEngine* e, int32_t which, double* total_ms, int64_
 
 /* measurement hooks (bench / profiling only, never on the product path) */
 int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len);   /* also fills the KV pages with pseudo-random bf16 */
+/* sealed KV pages (csrc/attn.hip kv_seal): out6 = {complete K pages of the live dialogues x kv heads x
+ * layers, of which NOT sealed (a lane's 128 values held more than 8 distinct high bytes: read as bf16), the same for V,
+ * number of layers whose K reads / V reads currently take the sealed pages (the read policy switches a layer back to bf16
+ * reads when more than 1 in 8 of its pages did not seal)}.  MTTS_ESTATE when the engine keeps none (fp32 / fp16 engines,
+ * MTTS_KV_PACK=0). */
+int32_t mtts_debug_kv_pack_stats(MttsEngine* e, int64_t* out6);
 /* train of `iters` launches of one decode attention pass (1 scores, 2 P.V) at the current state; when the product would
  * run the fused q/k/v epilogue at this size the train does too and overwrites the current position's K/V rows:
  * call it only when no further step follows */
@@ -212,6 +218,12 @@ int32_t mtts_k_rope_kvwrite(const void* dev_qkv, const int32_t* host_pos, const 
 int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const void* dev_v, const int32_t* host_lens,
                                  const int32_t* host_page_table, int32_t R, int32_t Lmax, int32_t nq, int32_t nkv,
                                  void* dev_out, void* stream);
+/* The sealed page format on its own: dev_pages = npages x 16 KiB (a page as the cache holds it: [16 units][64 lanes][16 B]),
+ * dev_sealed = npages x 13 KiB ([13 units][64 lanes][16 B]: units 0-7 the low bytes of the lane's 128 values in order,
+ * 8-11 one code nibble per value (byte 4j+k: low nibble = value 8j+k, high nibble = value 8j+4+k; code = sign << 3 | index),
+ * unit 12 = 8 dictionary bytes ((bf16 >> 8) & 0x7f, ascending), 4 zero bytes, a 32-bit flag: != 0 = the lane did not fit
+ * and the rest of its sealed data is undefined).  Lossless: value = sign << 15 | dictionary[index] << 8 | low byte. */
+int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, void* stream);
 /* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
 int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,
                       const void* dev_history_bitmap, const MttsSamplerCfg* cfg,

@@ -13,6 +13,165 @@
 // HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.
 #include "common.h"
 
+// ---------------------------------------------------------------------------------------------------
+// Sealed pages (common.h: MTTS_PKU).  A bf16 value is [sign | exponent 8 | mantissa 7]; over the 128 values one lane
+// reads from a page (a K row; 32 tokens x 4 dims of V) the LOW byte (exponent bit 0 + mantissa) is incompressible, but
+// the high byte without its sign (exponent bits 7..1) takes only a handful of distinct values.  A sealed page stores the
+// low bytes, a 4-bit code per value (sign, index) and the lane's dictionary of up to 8 such bytes: 13 bits per value,
+// exact.  Unpacking one 16-byte unit (8 values) is 12 VALU instructions: the dictionary look-up is a v_perm_b32 whose
+// selector is the masked code word, the sign is and-ed back in, two more v_perm interleave high and low bytes.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t u4c(const u32x4_t& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+// unit j (0..15, compile-time) of the lane's page from its 13 packed registers -> the 4 dwords of the bf16 form
+__device__ __forceinline__ void pk_unit(const u32x4_t* pk, int j, uint32_t w[4]) {
+    const uint32_t L0 = u4c(pk[j >> 1], 2 * (j & 1)), L1 = u4c(pk[j >> 1], 2 * (j & 1) + 1);
+    const uint32_t N = u4c(pk[8 + (j >> 2)], j & 3);
+    const uint32_t lo = pk[12].x, hi = pk[12].y;
+    const uint32_t HA = ((N & 0x08080808u) << 4) | __builtin_amdgcn_perm(hi, lo, N & 0x07070707u);
+    const uint32_t HB = (N & 0x80808080u) | __builtin_amdgcn_perm(hi, lo, (N >> 4) & 0x07070707u);
+    w[0] = __builtin_amdgcn_perm(HA, L0, 0x05010400u);
+    w[1] = __builtin_amdgcn_perm(HA, L0, 0x07030602u);
+    w[2] = __builtin_amdgcn_perm(HB, L1, 0x05010400u);
+    w[3] = __builtin_amdgcn_perm(HB, L1, 0x07030602u);
+}
+
+// One lane's share of a page (16 units of 16 B, 64 lanes apart) -> its sealed form (13 units).
+__device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
+    u32x4_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = raw[j * 64];
+    unsigned long long b0 = 0ull, b1 = 0ull;                  // which of the 128 possible high bytes occur
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t e = (u4c(v[j], c) >> (8 + 16 * h)) & 0x7fu;
+                if (e & 64u) b1 |= 1ull << (e & 63u);
+                else b0 |= 1ull << e;
+            }
+    const int n0 = __popcll(b0), n = n0 + __popcll(b1);
+    if (n > 8) {                                              // does not fit: readers take the bf16 page
+        pk[12 * 64] = u32x4_t{0u, 0u, 0u, 1u};
+        return false;
+    }
+    unsigned long long dict = 0ull;                           // entry i = the i-th smallest high byte present
+    {
+        unsigned long long t0 = b0, t1 = b1;
+        for (int i = 0; i < n; ++i) {
+            uint32_t e;
+            if (t0) { e = __ffsll((long long)t0) - 1; t0 &= t0 - 1; }
+            else { e = 64 + __ffsll((long long)t1) - 1; t1 &= t1 - 1; }
+            dict |= (unsigned long long)e << (8 * i);
+        }
+    }
+    auto code = [&](uint32_t half) -> uint32_t {              // 16-bit value -> sign << 3 | rank of its high byte
+        const uint32_t e = (half >> 8) & 0x7fu;
+        const uint32_t rank = (e & 64u) ? n0 + __popcll(b1 & ((1ull << (e & 63u)) - 1ull)) : __popcll(b0 & ((1ull << e) - 1ull));
+        return ((half >> 12) & 8u) | rank;
+    };
+    uint32_t lowp[32], nib[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint32_t N = 0u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                         // group A = dwords 0,1 of the unit, B = dwords 2,3
+            uint32_t L = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t half = (u4c(v[j], 2 * g + (k >> 1)) >> (16 * (k & 1))) & 0xffffu;
+                L |= (half & 0xffu) << (8 * k);
+                N |= code(half) << (8 * k + 4 * g);
+            }
+            lowp[2 * j + g] = L;
+        }
+        nib[j] = N;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pk[u * 64] = u32x4_t{lowp[4 * u], lowp[4 * u + 1], lowp[4 * u + 2], lowp[4 * u + 3]};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pk[(8 + u) * 64] = u32x4_t{nib[4 * u], nib[4 * u + 1], nib[4 * u + 2], nib[4 * u + 3]};
+    pk[12 * 64] = u32x4_t{(uint32_t)dict, (uint32_t)(dict >> 32), 0u, 0u};
+    return true;
+}
+// counters per layer: {K pages sealed, K pages with a lane that did not fit, the same for V} (the engine's read policy)
+__device__ __forceinline__ void seal_count(bool fit, unsigned long long* __restrict__ cnt, int layer, int wave, int lane) {
+    const bool all = !__any(!fit);
+    if (cnt && lane == 0) atomicAdd(cnt + layer * 4 + wave * 2 + (all ? 0 : 1), 1ull);
+}
+
+// Seal the page a row's token has just completed ((pos & 63) == 63), for every layer and kv head: grid = (R, nkv, L),
+// block 128 = the K wave and the V wave.  Runs at the end of a forward pass (decode step or prefill pass alike).
+__global__ __launch_bounds__(128) void kv_seal_rows_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
+                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack,
+                                                           const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta,
+                                                           int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
+                                                           unsigned long long* __restrict__ cnt) {
+    const RowMeta m = meta[blockIdx.x];
+    if (m.seq < 0 || (m.pos & 63) != 63) return;
+    const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int page = page_table[(size_t)m.seq * max_pages + (m.pos >> 6)];
+    const size_t pi = (size_t)kvh * total_pages + page;
+    const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                               (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+    seal_count(fit, cnt, layer, wave, lane);
+}
+// Every physical page (measurement hook: after the caches were filled behind the engine's back).  grid = (pages, nkv, L)
+__global__ __launch_bounds__(128) void kv_seal_all_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
+                                                          u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack, int total_pages,
+                                                          size_t raw_layer, size_t pk_layer, unsigned long long* __restrict__ cnt) {
+    const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t pi = (size_t)kvh * total_pages + blockIdx.x;
+    const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                               (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+    seal_count(fit, cnt, layer, wave, lane);
+}
+// Test hook: `npages` pages in a row (bf16 form, 16 KiB each) -> their sealed forms (13 KiB each).  grid = pages, block 64
+__global__ __launch_bounds__(64) void kv_seal_pages_kernel(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
+    seal_lane(raw + (size_t)blockIdx.x * (MTTS_PAGE * MTTS_HD / 8) + threadIdx.x, pk + (size_t)blockIdx.x * (MTTS_PKU * 64) + threadIdx.x);
+}
+void launch_kv_seal_pages(const void* raw, void* pk, int npages, hipStream_t st) {
+    hipLaunchKernelGGL(kv_seal_pages_kernel, dim3(npages), dim3(64), 0, st, (const u32x4_t*)raw, (u32x4_t*)pk);
+}
+// Debug hook: how many of the complete pages of the live sequences are sealed / had a lane that did not fit.
+// grid = (slots, nkv, L), block 64; out = {K pages, K pages not sealed, V pages, V pages not sealed}
+__global__ __launch_bounds__(64) void kv_pack_count_kernel(const u32x4_t* __restrict__ kpack, const u32x4_t* __restrict__ vpack,
+                                                           const int32_t* __restrict__ page_table, const int32_t* __restrict__ complete,
+                                                           int max_pages, int total_pages, size_t pk_layer, unsigned long long* __restrict__ out) {
+    const int b = blockIdx.x, kvh = blockIdx.y, layer = blockIdx.z, lane = threadIdx.x;
+    unsigned long long n = 0, dk = 0, dv = 0;
+    for (int pg = 0; pg < complete[b]; ++pg) {
+        const size_t pi = (size_t)kvh * total_pages + page_table[(size_t)b * max_pages + pg];
+        const u32x4_t fk = kpack[layer * pk_layer + pi * (MTTS_PKU * 64) + 12 * 64 + lane];
+        const u32x4_t fv = vpack[layer * pk_layer + pi * (MTTS_PKU * 64) + 12 * 64 + lane];
+        n += 1;
+        dk += __any(fk.w != 0u) ? 1 : 0;
+        dv += __any(fv.w != 0u) ? 1 : 0;
+    }
+    if (lane == 0 && n) {
+        atomicAdd(out + 0, n); atomicAdd(out + 1, dk); atomicAdd(out + 2, n); atomicAdd(out + 3, dv);
+    }
+}
+void launch_kv_pack_count(const void* kpack, const void* vpack, const int32_t* page_table, const int32_t* complete, int B, int max_pages,
+                          int total_pages, int nkv, int L, unsigned long long* out, hipStream_t st) {
+    const size_t pk_layer = (size_t)total_pages * nkv * (MTTS_PKU * 64);
+    hipLaunchKernelGGL(kv_pack_count_kernel, dim3(B, nkv, L), dim3(64), 0, st, (const u32x4_t*)kpack, (const u32x4_t*)vpack, page_table,
+                       complete, max_pages, total_pages, pk_layer, out);
+}
+void launch_kv_seal_rows(const void* kcache, const void* vcache, void* kpack, void* vpack, const int32_t* page_table,
+                         const RowMeta* meta, int R, int max_pages, int total_pages, int nkv, int L, unsigned long long* cnt, hipStream_t st) {
+    const size_t raw_layer = (size_t)total_pages * nkv * (MTTS_PAGE * MTTS_HD / 8), pk_layer = (size_t)total_pages * nkv * (MTTS_PKU * 64);
+    hipLaunchKernelGGL(kv_seal_rows_kernel, dim3(R, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
+                       (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, max_pages, total_pages, raw_layer, pk_layer, cnt);
+}
+void launch_kv_seal_all(const void* kcache, const void* vcache, void* kpack, void* vpack, int total_pages, int nkv, int L,
+                        unsigned long long* cnt, hipStream_t st) {
+    const size_t raw_layer = (size_t)total_pages * nkv * (MTTS_PAGE * MTTS_HD / 8), pk_layer = (size_t)total_pages * nkv * (MTTS_PKU * 64);
+    hipLaunchKernelGGL(kv_seal_all_kernel, dim3(total_pages, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
+                       (u32x4_t*)kpack, (u32x4_t*)vpack, total_pages, raw_layer, pk_layer, cnt);
+}
+
 
 // grid = (ceil(pages/4), nkv, R); block 256 = 4 waves, one page (64 tokens) per wave,
 // one token per lane: K page is [d/8][token][8] so lane t's 16 loads are 16 B each
@@ -62,11 +221,12 @@ __device__ __forceinline__ void fuse_norm_rope(const QkvFuse& f, const FuseVec& 
 
 // FUSED (decode rows): q comes from the qkv GEMM's slabs (reduce, RMSNorm, RoPE done here, one head per wave), and the
 // block whose pages hold position `pos` also produces the new K row, writes it to the cache and uses it from LDS.
-template <int G, bool FUSED>
+// PK: pages before the one that receives this step's token are complete, hence sealed: 13 loads per lane instead of 16.
+template <int G, bool FUSED, bool PK>
 __global__ __launch_bounds__(256) void attn_scores_kernel(
     const uint16_t* __restrict__ qbuf, u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
     const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
-    int total_pages, int nq, int nkv, float scale, QkvFuse f) {
+    int total_pages, int nq, int nkv, float scale, QkvFuse f, const u32x4_t* __restrict__ kpack) {
     __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
     __shared__ __attribute__((aligned(16))) uint16_t knew[MTTS_HD];
     const int r = blockIdx.z, kvh = blockIdx.y;
@@ -79,13 +239,21 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     const int pg = blockIdx.x * 4 + wave;
     // K loads first (they only need the page index); q is staged through LDS while they fly
     u32x4_t kv[16];
+    const int own_pg = m.pos >> 6;                    // page that receives this step's token
+    bool packed = PK && pg < own_pg;                  // (wave-uniform)
+    const u32x4_t* kp = nullptr;
     if (pg < npages) {
         const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+        kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+        if (packed) {
+            const u32x4_t* pp = kpack + ((size_t)kvh * total_pages + page) * (MTTS_PKU * 64) + lane;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+            for (int j = 0; j < MTTS_PKU; ++j) kv[j] = __builtin_nontemporal_load(pp + j * 64);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+        }
     }
-    const int own_pg = m.pos >> 6;                    // page that receives this step's token
     if (FUSED) {
         const bool own = (own_pg >> 2) == (int)blockIdx.x;
         for (int hh = wave; hh < G + (own ? 1 : 0); hh += 4) {
@@ -119,22 +287,44 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) kv[j] = *(const u32x4_t*)&knew[8 * j];
     }
+    if (PK && packed && __any(kv[12].w != 0u)) {      // a row of this page did not fit the sealed form: take the bf16 page
+        packed = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+    }
     float acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.f;
     // v_dot2c_f32_bf16: two bf16 products per lane-op, fp32 accumulate, no unpacking.
     // q is read as a wave-uniform (broadcast) 16-byte LDS word per 8 dims.
+    if (PK && packed) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 16; ++j) {
+            uint32_t w[4];
+            pk_unit(kv, j, w);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
-            acc[g] = dot2bf(kv[j].x, q.x, acc[g]);
-            acc[g] = dot2bf(kv[j].y, q.y, acc[g]);
-            acc[g] = dot2bf(kv[j].z, q.z, acc[g]);
-            acc[g] = dot2bf(kv[j].w, q.w, acc[g]);
+            for (int g = 0; g < G; ++g) {
+                const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
+                acc[g] = dot2bf(w[0], q.x, acc[g]);
+                acc[g] = dot2bf(w[1], q.y, acc[g]);
+                acc[g] = dot2bf(w[2], q.z, acc[g]);
+                acc[g] = dot2bf(w[3], q.w, acc[g]);
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the q reads from being hoisted into 100s of VGPRs
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
+                acc[g] = dot2bf(kv[j].x, q.x, acc[g]);
+                acc[g] = dot2bf(kv[j].y, q.y, acc[g]);
+                acc[g] = dot2bf(kv[j].z, q.z, acc[g]);
+                acc[g] = dot2bf(kv[j].w, q.w, acc[g]);
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the q reads from being hoisted into 100s of VGPRs
+        }
     }
     const int tok = pg * MTTS_PAGE + lane;
     const bool valid = tok < len;
@@ -164,11 +354,11 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 // d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
 // FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
 // writes it to the cache and patches it into the page it has just loaded.
-template <int G, bool FUSED>
+template <int G, bool FUSED, bool PK>
 __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
-    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f) {
+    int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f, const u32x4_t* __restrict__ vpack) {
     __shared__ float red[PV_WAVES][G][MTTS_HD];
     __shared__ uint16_t pbuf[PV_WAVES][G][MTTS_PAGE];
     __shared__ __attribute__((aligned(16))) uint16_t vnew[MTTS_HD];
@@ -184,13 +374,23 @@ __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
     // V loads of this wave's first page go out before the softmax statistics are reduced
     u32x4_t vv[16];
     int pg = chunk * ATT_PB + wave * (ATT_PB / PV_WAVES);
-    if (pg < npages) {
-        const int page = page_table[(size_t)m.seq * max_pages + pg];
-        const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
-    }
     const int own_pg = m.pos >> 6;
+    bool packed = false;
+    const u32x4_t* vp = nullptr;
+    auto load_page = [&]() {                          // complete pages are sealed: 13 loads per lane instead of 16
+        const int page = page_table[(size_t)m.seq * max_pages + pg];
+        vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+        packed = PK && pg < own_pg;
+        if (packed) {
+            const u32x4_t* pp = vpack + ((size_t)kvh * total_pages + page) * (MTTS_PKU * 64) + lane;
+#pragma unroll
+            for (int it = 0; it < MTTS_PKU; ++it) vv[it] = __builtin_nontemporal_load(pp + it * 64);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+        }
+    };
+    if (pg < npages) load_page();
     const bool own_wave = FUSED && own_pg >= pg && own_pg < pg + ATT_PB / PV_WAVES;       // one wave per (row, kv head)
     if (own_wave) {
         float a, b;
@@ -225,12 +425,7 @@ __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
 #pragma unroll 1
     for (int pp = 0; pp < ATT_PB / PV_WAVES; ++pp, ++pg) {
         if (pg >= npages) break;
-        if (pp > 0) {
-            const int page = page_table[(size_t)m.seq * max_pages + pg];
-            const u32x4_t* vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
-        }
+        if (pp > 0) load_page();
         if (own_wave && pg == own_pg) {
             // the page was loaded before the new row reached the cache: patch the token's half of its pair
             __builtin_amdgcn_wave_barrier();
@@ -264,15 +459,36 @@ __global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (PK && packed && __any(vv[12].w != 0u)) {  // a lane's values did not fit the sealed form: take the bf16 page
+            packed = false;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+            for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+        }
+        if (PK && packed) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint32_t pp2 = ((const uint32_t*)&pbuf[wave][g][0])[it * 2 + sub];
-                acc[g][0] = dot2bf(vv[it].x, pp2, acc[g][0]);
-                acc[g][1] = dot2bf(vv[it].y, pp2, acc[g][1]);
-                acc[g][2] = dot2bf(vv[it].z, pp2, acc[g][2]);
-                acc[g][3] = dot2bf(vv[it].w, pp2, acc[g][3]);
+            for (int it = 0; it < 16; ++it) {
+                uint32_t w[4];
+                pk_unit(vv, it, w);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t pp2 = ((const uint32_t*)&pbuf[wave][g][0])[it * 2 + sub];
+                    acc[g][0] = dot2bf(w[0], pp2, acc[g][0]);
+                    acc[g][1] = dot2bf(w[1], pp2, acc[g][1]);
+                    acc[g][2] = dot2bf(w[2], pp2, acc[g][2]);
+                    acc[g][3] = dot2bf(w[3], pp2, acc[g][3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t pp2 = ((const uint32_t*)&pbuf[wave][g][0])[it * 2 + sub];
+                    acc[g][0] = dot2bf(vv[it].x, pp2, acc[g][0]);
+                    acc[g][1] = dot2bf(vv[it].y, pp2, acc[g][1]);
+                    acc[g][2] = dot2bf(vv[it].z, pp2, acc[g][2]);
+                    acc[g][3] = dot2bf(vv[it].w, pp2, acc[g][3]);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -524,7 +740,7 @@ template <int G>
 static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                           int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                          const QkvFuse* fuse, int phase, hipStream_t st) {
+                          const QkvFuse* fuse, int phase, hipStream_t st, const KvPack* pack) {
     if (phase == 11) {   // prefill tiles (32 consecutive positions of one dialogue per tile)
         dim3 ga((pages_bound + 3) / 4, nkv, R / MTTS_MAXR);
         hipLaunchKernelGGL((attn_prefill_scores_kernel<G>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (const u32x4_t*)kcache,
@@ -544,24 +760,26 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
         return;
     }
     const QkvFuse f = fuse ? *fuse : QkvFuse{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f};
+    const u32x4_t* kpk = pack ? (const u32x4_t*)pack->k : nullptr;
+    const u32x4_t* vpk = pack ? (const u32x4_t*)pack->v : nullptr;
+#define MTTS_SC(FU, PK)                                                                                                  \
+    hipLaunchKernelGGL((attn_scores_kernel<G, FU, PK>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache, \
+                       page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f, kpk)
+#define MTTS_PV(FU, PK)                                                                                                         \
+    hipLaunchKernelGGL((attn_pv_kernel<G, FU, PK>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats, \
+                       (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, vpk)
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
-        if (fuse)
-            hipLaunchKernelGGL((attn_scores_kernel<G, true>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache,
-                               page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f);
-        else
-            hipLaunchKernelGGL((attn_scores_kernel<G, false>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache,
-                               page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f);
+        if (fuse) { if (kpk) MTTS_SC(true, true); else MTTS_SC(true, false); }
+        else { if (kpk) MTTS_SC(false, true); else MTTS_SC(false, false); }
     }
     if (phase == 0 || phase == 2) {
         dim3 gb((pages_bound + ATT_PB - 1) / ATT_PB, nkv, R);
-        if (fuse)
-            hipLaunchKernelGGL((attn_pv_kernel<G, true>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
-        else
-            hipLaunchKernelGGL((attn_pv_kernel<G, false>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats,
-                               (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f);
+        if (fuse) { if (vpk) MTTS_PV(true, true); else MTTS_PV(true, false); }
+        else { if (vpk) MTTS_PV(false, true); else MTTS_PV(false, false); }
     }
+#undef MTTS_SC
+#undef MTTS_PV
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, (nq + 3) / 4), dim3(512), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
@@ -572,11 +790,11 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
 int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                const QkvFuse* fuse, int phase, hipStream_t st) {
+                const QkvFuse* fuse, int phase, hipStream_t st, const KvPack* pack) {
     int G = nq / nkv;
 #define MTTS_ATT(GG)                                                                                              \
     launch_attn_g<GG>(qbuf, kcache, vcache, page_table, meta, scores, stats, opart, out_packed, R, pages_bound,   \
-                      max_pages, total_pages, nchunks_max, nq, nkv, scale, fuse, phase, st)
+                      max_pages, total_pages, nchunks_max, nq, nkv, scale, fuse, phase, st, pack)
     if (G == 1) MTTS_ATT(1);
     else if (G == 2) MTTS_ATT(2);
     else if (G == 4) MTTS_ATT(4);

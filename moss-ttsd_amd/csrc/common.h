@@ -68,6 +68,13 @@ struct QkvFuse {
     float eps;
 };
 
+// Sealed KV pages (attn.hip: kv_seal): a COMPLETE page also exists in a 13-bit lossless form, 13 sixteen-byte units per
+// lane instead of 16 -- units 0..7 the low bytes of the lane's 128 values, 8..11 a 4-bit code per value (sign + index into
+// the lane's dictionary), unit 12 = {dictionary of up to 8 distinct "bf16 high byte without the sign" values, 0, flag};
+// flag != 0: the lane's values needed more than 8 entries, the page is read in its bf16 form.
+#define MTTS_PKU 13
+struct KvPack { void* k; void* v; };             // this layer's sealed K / V pages ([kv head][page][13][64][16 B]), or null
+
 // Per-row metadata of one forward pass.
 struct RowMeta {
     int32_t seq;     // sequence slot (page-table row), -1 = inactive row

@@ -49,7 +49,14 @@ void launch_fill_random_bf16(void* p, size_t n, uint32_t seed, hipStream_t st);
 int launch_attn(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                 const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
                 int pages_bound, int max_pages, int total_pages, int nchunks_max, int nq, int nkv, float scale,
-                const QkvFuse* fuse, int phase, hipStream_t st);
+                const QkvFuse* fuse, int phase, hipStream_t st, const KvPack* pack = nullptr);
+void launch_kv_seal_rows(const void* kcache, const void* vcache, void* kpack, void* vpack, const int32_t* page_table,
+                         const RowMeta* meta, int R, int max_pages, int total_pages, int nkv, int L, unsigned long long* cnt, hipStream_t st);
+void launch_kv_seal_all(const void* kcache, const void* vcache, void* kpack, void* vpack, int total_pages, int nkv, int L,
+                        unsigned long long* cnt, hipStream_t st);
+void launch_kv_seal_pages(const void* raw, void* pk, int npages, hipStream_t st);
+void launch_kv_pack_count(const void* kpack, const void* vpack, const int32_t* page_table, const int32_t* complete, int B, int max_pages,
+                          int total_pages, int nkv, int L, unsigned long long* out, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
 struct LoopState { int32_t step, done, continuous, B, error, gen_cap, forced_draw, logits_f32; };
 struct SampleScratch { uint32_t* hist; float* slice_val; int32_t* slice_idx; float* cand_val; int32_t* cand_idx; uint32_t* cand_n; int32_t* overflow; float* full_val; int32_t* full_idx; uint32_t* nuc_cnt; unsigned long long* nuc_mass; };
@@ -198,6 +205,16 @@ struct MttsEngine {
     std::vector<StepGraph> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graphs = true;
+    // sealed KV pages (attn.hip: kv_seal): every COMPLETE page also kept in a lossless 13-bit form the decode attention
+    // reads instead of the bf16 page (MTTS_KV_PACK=0: off, no second pool)
+    int kv_pack = 1;
+    void *kpack = nullptr, *vpack = nullptr;
+    size_t pk_layer_stride = 0;         // bytes per layer of a sealed pool
+    // read policy: a page that did not seal costs a wasted sealed read + the bf16 read (29 units instead of 16), so a
+    // layer whose K (or V) pages stop sealing (more than 1 in 8 since mtts_begin) goes back to bf16 reads; the sealer
+    // counts per layer {K sealed, K not, V sealed, V not}, mtts_sync_state looks at the counts (MTTS_KV_PACK=2: no policy)
+    unsigned long long *d_seal_cnt = nullptr, *h_seal_cnt = nullptr;
+    std::vector<char> pack_k_on, pack_v_on;
     int fuse_qkv_max = 1024;            // decode: q/k/v epilogue inside the attention kernels while rows x KV pages <= this
     int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
@@ -386,6 +403,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     e->device = device;
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
     if (const char* g = getenv("MTTS_FUSE_QKV_MAX")) e->fuse_qkv_max = atoi(g);
+    if (const char* g = getenv("MTTS_KV_PACK")) e->kv_pack = atoi(g);
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     if (const char* g = getenv("MTTS_SMALL_ROWS")) e->small_rows = std::min(std::max(atoi(g), 0), SMALL_RP);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
@@ -460,6 +478,16 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     } else {
         TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
         TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
+        if (e->kv_pack) {
+            e->pk_layer_stride = (size_t)e->total_pages * e->nkv * MTTS_PKU * 64 * 16;
+            TRY(dalloc((uint8_t**)&e->kpack, e->pk_layer_stride * e->L));
+            TRY(dalloc((uint8_t**)&e->vpack, e->pk_layer_stride * e->L));
+            TRY(dalloc(&e->d_seal_cnt, (size_t)e->L * 4));
+            HIPCHK(hipHostMalloc((void**)&e->h_seal_cnt, (size_t)e->L * 4 * sizeof(unsigned long long)));
+            memset(e->h_seal_cnt, 0, (size_t)e->L * 4 * sizeof(unsigned long long));
+            e->pack_k_on.assign(e->L, 1);
+            e->pack_v_on.assign(e->L, 1);
+        }
     }
     TRY(dalloc(&e->d_page_table, (size_t)c->max_batch * e->max_pages));
     e->h_page_table.assign((size_t)c->max_batch * e->max_pages, 0);
@@ -513,12 +541,14 @@ int32_t mtts_engine_destroy(MttsEngine* e) {
     }
     void* ptrs[] = {e->partial2, e->x2, e->act_rm, e->head0, e->heads17, e->final_norm, e->rope_cos, e->rope_sin, (void*)e->d_tables, e->partial, e->x,
                     e->xn, e->xh, e->hlast, e->attn_p, e->act_p, e->qbuf, e->logits0, e->logits17, e->join_logits0, e->join_logits17, e->scores, e->stats,
-                    e->opart, e->kcache, e->vcache, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
+                    e->opart, e->kcache, e->vcache, e->kpack, e->vpack, e->d_page_table, e->d_seqs, e->d_meta, e->d_ls, e->d_decisions,
                     e->d_cur, e->d_gen, e->d_declog, e->d_forced, e->d_tf, e->d_bitmaps, e->d_scfg, e->d_pf_tokens,
                     e->d_pf_meta};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_ls) hipHostFree(e->h_ls);
     if (e->h_seqs) hipHostFree(e->h_seqs);
+    if (e->h_seal_cnt) hipHostFree(e->h_seal_cnt);
+    if (e->d_seal_cnt) hipFree(e->d_seal_cnt);
     free_scratch(e->sscr);
     drop_graphs(e);
     if (e->cap_stream) hipStreamDestroy(e->cap_stream);
@@ -693,6 +723,22 @@ static void prof_end(MttsEngine* e, hipStream_t st, hipEvent_t a) {
 // their prologue.  The residual stream alternates between two buffers (a prologue's block (0,0) writes x' while the
 // other blocks still read x); the qkv slabs live in `partial` (the fused attention epilogue reads them), the o_proj /
 // down_proj slabs in `partial2`.  Same arithmetic as forward_rows, operation for operation.
+// a new run: sealed reads everywhere, counts from zero
+static int pack_policy_reset(MttsEngine* e, hipStream_t st) {
+    if (!e->d_seal_cnt) return 0;
+    HIPCHK(hipMemsetAsync(e->d_seal_cnt, 0, (size_t)e->L * 4 * sizeof(unsigned long long), st));
+    bool changed = false;
+    for (int n = 0; n < e->L; ++n) { changed |= !e->pack_k_on[n] || !e->pack_v_on[n]; e->pack_k_on[n] = 1; e->pack_v_on[n] = 1; }
+    if (changed) drop_graphs(e);
+    return 0;
+}
+// this layer's sealed pools, each null where the read policy (or MTTS_KV_PACK=0) says bf16 pages
+static KvPack layer_pack(MttsEngine* e, int n) {
+    KvPack pk{nullptr, nullptr};
+    if (e->kpack && e->pack_k_on[n]) pk.k = (uint8_t*)e->kpack + e->pk_layer_stride * n;
+    if (e->vpack && e->pack_v_on[n]) pk.v = (uint8_t*)e->vpack + e->pk_layer_stride * n;
+    return pk;
+}
 static bool small_path_fits(MttsEngine* e) {
     const int H = e->H;
     if (H > 8192 || H % 8 || e->I % 8) return false;
@@ -718,6 +764,7 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
         const bool fused = e->B * pages_bound <= e->fuse_qkv_max;
         const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
                          (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
+        const KvPack pk = layer_pack(e, n);
         if (!fused)
             launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
                             kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, st);
@@ -726,7 +773,7 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
             prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
                             pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
-                            fused ? &fz : nullptr, phase, st))
+                            fused ? &fz : nullptr, phase, st, (pk.k || pk.v) ? &pk : nullptr))
                 return fail(MTTS_EINVAL, "attention group size not built");
             prof_end(e, st, ev);
         }
@@ -744,6 +791,8 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
         pd.xrows = (const uint16_t*)e->act_rm;
         launch_gemv_small(EPI_PARTIAL, PRO_ROWS, e->p_d, l.wd, I, Hp, Hp, e->partial2, nullptr, pd, st);
     }
+    if (e->kpack)                                      // rows whose token completed a KV page: seal it (all layers)
+        launch_kv_seal_rows(e->kcache, e->vcache, e->kpack, e->vpack, e->d_page_table, d_meta, R, e->max_pages, e->total_pages, nkv, e->L, e->d_seal_cnt, st);
     SmallPro ph = base;                                // final norm (+ the last down_proj slabs) in front of the 8 heads
     ph.x_in = xa; ph.x_out = nullptr; ph.slabs = e->partial2; ph.ksplit = e->p_d.ksplit; ph.norm_w = (const uint16_t*)e->final_norm;
     // (same plan as the general path: a different K partition over the waves would change the fp32 sums, and with them
@@ -792,12 +841,15 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         // decode rows are one dialogue each (phases 1,2); prefill tiles are 32 consecutive positions of one
         // dialogue and share their K/V pages (phases 11,12,13: chunks of ATT_PF pages)
         const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
+        // decode rows read complete pages in their sealed form; prefill rows (a page may be completed by the pass
+        // itself) read the bf16 pages
+        const KvPack pk = layer_pack(e, n);
         for (int phase = 1; phase <= 3; ++phase) {
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
             if (launch_attn(e->qbuf, kc, vc, e->d_page_table, d_meta, e->scores, e->stats, e->opart, e->attn_p, R,
                             pages_bound, e->max_pages, e->total_pages, e->nchunks_max, nq, nkv, scale,
-                            fused ? &fz : nullptr, ph0 + phase, st))
+                            fused ? &fz : nullptr, ph0 + phase, st, (heads == 1 && (pk.k || pk.v)) ? &pk : nullptr))
                 return fail(MTTS_EINVAL, "attention group size not built");
             if (phase < 3) prof_end(e, st, ev);
         }
@@ -819,6 +871,8 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         const void* nw = lastl ? e->final_norm : e->layers[n + 1].ln_in;
         launch_resid_norm(e->partial, ks_d, Hp, e->x, nw, e->xn, lastl ? e->hlast : nullptr, d_meta, R, H, eps, st);
     }
+    if (e->kpack)                                      // rows whose token completed a KV page: seal it (all layers)
+        launch_kv_seal_rows(e->kcache, e->vcache, e->kpack, e->vpack, e->d_page_table, d_meta, R, e->max_pages, e->total_pages, nkv, e->L, e->d_seal_cnt, st);
     if (heads) {
         const void* xin = e->xn;
         int hmb = mb;
@@ -881,6 +935,7 @@ int32_t mtts_begin(MttsEngine* e, const int64_t* ids, const uint8_t* mask, int32
     // pages are taken now, the rest on demand as the dialogues grow (issue_steps)
     for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = b < B; }
     e->pending_edits.n = 0;            // edits queued by a run that failed (MTTS_ENOMEM before its flush) belong to released pages
+    TRY(pack_policy_reset(e, st));
     for (int b = 0; b < B; ++b) {
         const int need = (e->n_real[b] + max_steps + MTTS_PAGE - 1) / MTTS_PAGE;
         if (need > e->max_pages) return fail(MTTS_ENOMEM, "row %d needs %d KV pages, a sequence holds at most %d (max_seq_len %d)", b, need, e->max_pages, e->cfg.max_seq_len);
@@ -1060,7 +1115,18 @@ int32_t mtts_sync_state(MttsEngine* e, int32_t* steps_done, int32_t* all_finishe
     HIPCHK(hipMemcpyAsync(e->h_ls, e->d_ls, sizeof(LoopState), hipMemcpyDeviceToHost, S(stream)));
     // (both copies ride the caller's stream into pinned memory: no null-stream copy that would serialise with the codec leg)
     if (!e->continuous) HIPCHK(hipMemcpyAsync(e->h_seqs, e->d_seqs, e->B * sizeof(SeqState), hipMemcpyDeviceToHost, S(stream)));
+    if (e->d_seal_cnt) HIPCHK(hipMemcpyAsync(e->h_seal_cnt, e->d_seal_cnt, (size_t)e->L * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S(stream)));
     HIPCHK(hipStreamSynchronize(S(stream)));
+    if (e->d_seal_cnt && e->kv_pack == 1) {
+        bool changed = false;
+        for (int n = 0; n < e->L; ++n) {
+            const unsigned long long* c = e->h_seal_cnt + (size_t)n * 4;
+            const bool k_on = c[0] + c[1] < 16 || c[1] * 8 <= c[0] + c[1], v_on = c[2] + c[3] < 16 || c[3] * 8 <= c[2] + c[3];
+            changed |= (k_on != (bool)e->pack_k_on[n]) || (v_on != (bool)e->pack_v_on[n]);
+            e->pack_k_on[n] = k_on; e->pack_v_on[n] = v_on;
+        }
+        if (changed) drop_graphs(e);                 // the captured steps hold the old choice of kernels
+    }
     if (e->h_ls->error) return fail(MTTS_EINVAL, "device sampler error %d: more than 4096 candidate tokens (set top_k so that the k-th score's radix bin holds <= 4096 tokens)", e->h_ls->error);
     if (!e->continuous) {
         // static batch (mtts_generate semantics): a finished row only emits padding from here on and never touches
@@ -1210,6 +1276,7 @@ int32_t mtts_sched_open(MttsEngine* e, int32_t B, int32_t gen_cap, const MttsSam
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < e->cfg.max_batch; ++b) { pool_release(e, b); e->slot_live[b] = 0; }
     e->pending_edits.n = 0;
+    TRY(pack_policy_reset(e, st));
     std::vector<SeqState> ss(MTTS_RCAP, SeqState{-1, 0, 0, 0, 0, 0, 0, 0, 0});
     HIPCHK(hipMemcpyAsync(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice, st));
     LoopState ls{0, 0, 1, B, 0, e->gen_cap, 0, e->f32 ? 1 : 0};
@@ -1606,13 +1673,60 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
     HIPCHK(hipMemcpy(pt, hpt.data(), hpt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(lens, host_lens, R * 4, hipMemcpyHostToDevice));
     launch_pack_kv_pages(dev_k, dev_v, kc, vc, pt, lens, R, Lmax, nkv, max_pages, total_pages, st);
+    // like the engine: complete pages are read in their sealed form unless MTTS_KV_PACK=0
+    KvPack pk{nullptr, nullptr};
+    const char* g = getenv("MTTS_KV_PACK");
+    if (!g || atoi(g) != 0) {
+        uint8_t *kp = nullptr, *vp = nullptr;
+        const size_t pk_n = (size_t)total_pages * nkv * MTTS_PKU * 64 * 16;
+        TRY(hb.get(&kp, pk_n)); TRY(hb.get(&vp, pk_n));
+        launch_kv_seal_all(kc, vc, kp, vp, total_pages, nkv, 1, nullptr, st);
+        pk = KvPack{kp, vp};
+    }
     const float scale = 1.0f / sqrtf((float)MTTS_HD);
     if (launch_attn(dev_q, kc, vc, pt, meta, scores, stats, opart, outp, MTTS_MAXR, pages_bound, max_pages, total_pages, nch, nq, nkv,
-                    scale, nullptr, 0, st))
+                    scale, nullptr, 0, st, pk.k ? &pk : nullptr))
         return fail(MTTS_EINVAL, "attention group size not built (1, 2, 4)");
     launch_unpack_rows(outp, dev_out, R, nq * MTTS_HD, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    return MTTS_OK;
+}
+
+// Test hook for the sealed page format (attn.hip: seal_lane): `npages` bf16 pages of 16 KiB -> sealed pages of 13 KiB.
+extern "C" int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, void* stream) {
+    if (!dev_pages || !dev_sealed || npages < 1) return fail(MTTS_EINVAL, "kv_seal: bad argument");
+    launch_kv_seal_pages(dev_pages, dev_sealed, npages, S(stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return MTTS_OK;
+}
+
+// Debug hook: out6 = {complete K pages of the live sequences (x kv heads x layers), of which not sealed (a lane did not
+// fit: read as bf16), the same two numbers for V, layers whose K / V reads currently use the sealed pages}.
+// MTTS_ESTATE when the engine runs without sealed pages.
+extern "C" int32_t mtts_debug_kv_pack_stats(MttsEngine* e, int64_t* out6) {
+    if (!e || !out6) return fail(MTTS_EINVAL, "null argument");
+    if (!e->kpack) return fail(MTTS_ESTATE, "the engine keeps no sealed pages (fp32 / fp16 engine, or MTTS_KV_PACK=0)");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<SeqState> ss(MTTS_RCAP);
+    HIPCHK(hipMemcpy(ss.data(), e->d_seqs, ss.size() * sizeof(SeqState), hipMemcpyDeviceToHost));
+    std::vector<int32_t> complete(e->B, 0);
+    for (int b = 0; b < e->B; ++b)
+        if (e->slot_live[b]) complete[b] = std::min(ss[b].kv_len >> 6, e->n_pages[b]);
+    HookBufs hb;
+    int32_t* dc = nullptr; unsigned long long* dout = nullptr;
+    TRY(hb.get(&dc, e->B)); TRY(hb.get(&dout, 4));
+    HIPCHK(hipMemcpy(dc, complete.data(), e->B * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dout, 0, 32));
+    launch_kv_pack_count(e->kpack, e->vpack, e->d_page_table, dc, e->B, e->max_pages, e->total_pages, e->nkv, e->L, dout, nullptr);
+    HIPCHK(hipGetLastError());
+    unsigned long long h[4];
+    HIPCHK(hipMemcpy(h, dout, 32, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out6[i] = (int64_t)h[i];
+    out6[4] = out6[5] = 0;
+    for (int n = 0; n < e->L; ++n) { out6[4] += e->pack_k_on[n]; out6[5] += e->pack_v_on[n]; }
     return MTTS_OK;
 }
 
@@ -1635,6 +1749,7 @@ extern "C" int32_t mtts_debug_set_kv_len(MttsEngine* e, int32_t kv_len) {
     HIPCHK(hipMemcpy(e->d_seqs, ss.data(), ss.size() * sizeof(SeqState), hipMemcpyHostToDevice));
     launch_fill_random_bf16(e->kcache, e->layer_stride * e->L, 0x1234u, nullptr);
     launch_fill_random_bf16(e->vcache, e->layer_stride * e->L, 0x9876u, nullptr);
+    if (e->kpack) launch_kv_seal_all(e->kcache, e->vcache, e->kpack, e->vpack, e->total_pages, e->nkv, e->L, nullptr, nullptr);
     HIPCHK(hipDeviceSynchronize());
     return MTTS_OK;
 }
@@ -1663,8 +1778,10 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
             const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)e->layers[layer].qn,
                              (const uint16_t*)e->layers[layer].kn, (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin,
                              e->cfg.rms_norm_eps};
+            const KvPack pk = layer_pack(e, layer);
             launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
-                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr, phase, nullptr);
+                        e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr, phase, nullptr,
+                        (pk.k || pk.v) ? &pk : nullptr);
         }
     };
     run(e->L);                               // warm-up

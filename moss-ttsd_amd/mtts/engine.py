@@ -244,6 +244,14 @@ class Engine:
         capi.check(self.lib.mtts_export_codes(self._h, int(first), int(n), out.data_ptr(), sp))
         return out
 
+    def kv_pack_stats(self):
+        """Sealed KV pages of the live dialogues -> dict(k_pages, k_unsealed, v_pages, v_unsealed, k_layers_on, v_layers_on)
+        (page x kv head x layer counts; `unsealed` = a lane did not fit the 13-bit form, the page is read as bf16;
+        `*_layers_on` = layers whose reads currently take the sealed pages)."""
+        o = np.zeros(6, dtype=np.int64)
+        capi.check(self.lib.mtts_debug_kv_pack_stats(self._h, o.ctypes.data))
+        return dict(zip(("k_pages", "k_unsealed", "v_pages", "v_unsealed", "k_layers_on", "v_layers_on"), (int(x) for x in o)))
+
     def debug_set_kv_len(self, n):
         capi.check(self.lib.mtts_debug_set_kv_len(self._h, int(n)))
 

@@ -1,0 +1,179 @@
+"""Sealed KV pages (csrc/attn.hip: seal_lane / pk_unit; include/mtts.h: mtts_k_kv_seal).  -m gpu.
+
+A complete KV page is kept a second time in a 13-bit form the decode attention reads instead of the bf16 page.  The form
+is LOSSLESS, so everything here is bit-for-bit: the format against its documented layout (decoded with numpy), the
+attention launches on sealed pages against the same launches on bf16 pages, the engine with the switch on against off."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from mtts import capi, synth  # noqa: E402
+from oracle import asteroid_oracle as ao  # noqa: E402
+
+
+def _bf16_bits(x):
+    return (np.ascontiguousarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def _decode_sealed(sealed):
+    """numpy restatement of the documented layout: sealed uint8 [pages, 13, 64, 16] -> (uint16 [pages, 64, 128] in the
+    lane's value order, flags [pages, 64])."""
+    P = sealed.shape[0]
+    low = sealed[:, 0:8].transpose(0, 2, 1, 3).reshape(P, 64, 128).astype(np.uint16)
+    nib = sealed[:, 8:12].transpose(0, 2, 1, 3).reshape(P, 64, 16, 4)            # [.., j, k]
+    code = np.concatenate([nib & 0xf, nib >> 4], axis=-1).reshape(P, 64, 128)     # value 8j + k / 8j + 4 + k
+    last = sealed[:, 12]                                                          # [P, 64, 16]
+    dic = last[..., :8].astype(np.uint16)
+    flag = last[..., 12:16].copy().view(np.uint32)[..., 0]
+    hi = np.take_along_axis(dic, (code & 7).astype(np.int64), axis=-1)
+    return ((code.astype(np.uint16) >> 3) << 15) | (hi << 8) | low, flag
+
+
+def _seal(pages_u16):
+    """uint16 [pages, 64 lanes, 128 values] (lane order) -> sealed uint8 [pages, 13, 64, 16] through the HIP kernel."""
+    P = pages_u16.shape[0]
+    raw = pages_u16.reshape(P, 64, 16, 8).transpose(0, 2, 1, 3)                    # [page][unit][lane][8 halves]
+    t = torch.from_numpy(np.ascontiguousarray(raw).view(np.int16)).cuda()
+    out = torch.zeros(P, 13, 64, 16, dtype=torch.uint8, device="cuda")
+    capi.check(capi.lib().mtts_k_kv_seal(t.data_ptr(), P, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_sealed_page_format_is_lossless_and_flags_what_does_not_fit():
+    rng = np.random.default_rng(5)
+    P = 12
+    x = rng.standard_normal((P, 64, 128)).astype(np.float32)
+    x[1] *= 1e-3
+    x[2] *= 300.0
+    x[3, :, ::7] = 0.0                                      # exact zeros next to normal values (RoPE cancellations)
+    x[4, :, 5] = -0.0
+    x[5] = np.where(rng.random((64, 128)) < 0.5, x[5], x[5] * 2.0 ** -9)   # two clusters of exponents
+    v = _bf16_bits(x)
+    # lanes built by hand: exactly 8 distinct high bytes (fits), 9 (does not), denormals, inf / nan patterns
+    e8 = np.array([0x3f, 0x3e, 0x3d, 0x3c, 0x3b, 0x20, 0x10, 0x00], dtype=np.uint16)
+    v[6, 0] = (e8[rng.integers(0, 8, 128)] << 8) | rng.integers(0, 256, 128) | (rng.integers(0, 2, 128) << 15)
+    v[6, 0, :8] = (e8 << 8) | 0x55
+    v[6, 1] = v[6, 0]
+    v[6, 1, 9] = 0x2a11                                     # a ninth high byte
+    v[6, 2] = rng.integers(0, 0x80, 128)                    # denormals: high byte 0
+    v[6, 3] = np.where(rng.random(128) < 0.5, 0x7f80, 0xffc1).astype(np.uint16)   # +inf and a negative NaN: high byte 0x7f
+    v[7] = rng.integers(0, 1 << 16, (64, 128))              # random bits: ~100 distinct high bytes per lane
+    got, flag = _decode_sealed(_seal(v))
+    assert flag[7].all()                                    # nothing of the random-bits page fits
+    assert flag[6, 1] == 1 and flag[6, 0] == 0 and flag[6, 2] == 0 and flag[6, 3] == 0
+    fits = flag == 0
+    assert fits[:5].mean() > 0.99                           # Gaussian lanes fit (a lane needs 9+ distinct exponent pairs not to)
+    assert np.array_equal(got[fits], v[fits])               # bit for bit, -0.0 / inf / nan / denormals included
+    # the dictionary is sorted ascending and holds exactly the distinct high bytes
+    s = _seal(v)
+    for pg, ln in [(0, 0), (6, 0), (3, 17)]:
+        want = np.unique((v[pg, ln] >> 8) & 0x7f)
+        assert list(s[pg, 12, ln, :len(want)]) == list(want)
+
+
+@pytest.mark.parametrize("nq,nkv", [(4, 2), (8, 2), (4, 4)])
+def test_decode_attention_on_sealed_pages_equals_bf16_pages_bit_for_bit(monkeypatch, nq, nkv):
+    """The three decode launches over a shuffled page table, ragged lengths, with rows that seal and rows that do not
+    (wide exponent ranges in K and in V): sealed pages on == off, every bit."""
+    lib = capi.lib()
+    rng = np.random.default_rng(100 + nq)
+    R, Lmax = 6, 1100
+    lens = np.array([1100, 1, 64, 65, 777, 1024], dtype=np.int32)
+    q = ao.round_bf16(rng.standard_normal((R, nq, 128)).astype(np.float32))
+    K = rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32)
+    V = rng.standard_normal((R, Lmax, nkv, 128)).astype(np.float32)
+    K[0, 100:140] *= (2.0 ** rng.integers(-40, 1, (40, nkv, 128))).astype(np.float32)      # tokens whose K row cannot seal
+    V[4, 200:300, :, 8:12] *= (2.0 ** rng.integers(-40, 1, (100, nkv, 4))).astype(np.float32)   # a V lane that cannot
+    K[1:, :, :, 3] = 0.0
+    K, V = ao.round_bf16(K), ao.round_bf16(V)
+    pages = (Lmax + 63) // 64
+    table = rng.permutation(R * pages).astype(np.int32).reshape(R, pages)
+    bf = lambda a: torch.from_numpy(_bf16_bits(a).view(np.int16)).cuda().view(torch.bfloat16)
+    qt, kt, vt = bf(q), bf(K), bf(V)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MTTS_KV_PACK", mode)
+        out = torch.zeros(R, nq * 128, dtype=torch.bfloat16, device="cuda")
+        capi.check(lib.mtts_k_paged_attn_decode(qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), lens.ctypes.data, table.ctypes.data,
+                                                R, Lmax, nq, nkv, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs[mode] = out.view(torch.int16).cpu().numpy()
+    assert np.array_equal(outs["0"], outs["1"])
+    assert np.abs(outs["1"]).max() > 0
+
+
+def test_engine_with_sealed_pages_equals_engine_without_and_pages_do_seal(monkeypatch):
+    """A 200-token prompt (3 complete pages from the prefill) + 150 decode steps (2 more sealed on the way), B = 3 ragged:
+    same tokens, same logits bits with MTTS_KV_PACK on and off; the counters show the pages exist and seal."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 77, emb_row_sigma=0.6, speech_boost=5.0)
+    rng = np.random.default_rng(3)
+    B, T = 3, 200
+    ids = np.full((B, T, 8), 1024, dtype=np.int64)
+    ids[:, :, 0] = rng.integers(0, cfg["vocab_size"] - 10, (B, T))
+    mask = np.ones((B, T), dtype=np.int64)
+    ids[1, :37] = [cfg.get("pad_token_id", 0)] + [1024] * 7
+    mask[1, :37] = 0
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MTTS_KV_PACK", mode)
+        eng = Engine(cfg, max_batch=4, max_seq_len=512)
+        eng.bind_state_dict(w)
+        out = eng.generate(ids, mask, T + 150, do_samples=[False] * 8)
+        l0, l17 = eng.read_logits()
+        st = eng.kv_pack_stats() if mode == "1" else None
+        res[mode] = (out, np.asarray(l0).copy(), np.asarray(l17).copy(), st)
+        if mode == "0":
+            with pytest.raises(capi.MttsError):
+                eng.kv_pack_stats()
+        eng.close()
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2])
+    st = res["1"][3]
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_kv_pack_stats_tiny.json"), "w") as f:
+        json.dump(st, f)
+    assert st["k_pages"] > 0 and st["k_pages"] == st["v_pages"]
+    assert st["k_unsealed"] <= 0.05 * st["k_pages"] and st["v_unsealed"] <= 0.05 * st["v_pages"], st
+
+
+def test_read_policy_turns_a_layer_back_to_bf16_pages_when_its_k_rows_do_not_seal(monkeypatch):
+    """k_norm weights spread over 24 binades: a K row then holds more than 8 distinct exponent pairs and no K page seals.
+    Results stay those of the bf16 pages; after the first host sync that has seen 16 pages the engine stops reading the
+    sealed K pages of those layers (V keeps sealing and keeps its sealed reads)."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 78, emb_row_sigma=0.6, speech_boost=5.0)
+    rng = np.random.default_rng(4)
+    kn = [k for k in w if k.endswith("k_norm.weight")]
+    assert len(kn) == cfg["num_hidden_layers"]
+    for k in kn:
+        scale = (2.0 ** rng.integers(-12, 13, w[k].shape)).astype(np.float32)
+        w[k] = (w[k] * scale).astype(np.float32)                  # powers of two: still exact bf16 values
+    B, T = 2, 700
+    ids = np.full((B, T, 8), 1024, dtype=np.int64)
+    ids[:, :, 0] = rng.integers(0, cfg["vocab_size"] - 10, (B, T))
+    mask = np.ones((B, T), dtype=np.int64)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MTTS_KV_PACK", mode)
+        eng = Engine(cfg, max_batch=2, max_seq_len=1024)
+        eng.bind_state_dict(w)
+        out = eng.generate(ids, mask, T + 40, do_samples=[False] * 8)
+        l0, l17 = eng.read_logits()
+        res[mode] = (out, np.asarray(l0).copy(), np.asarray(l17).copy(), eng.kv_pack_stats() if mode == "1" else None)
+        eng.close()
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2])
+    st = res["1"][3]
+    assert st["k_pages"] >= 2 * 10 * cfg["num_key_value_heads"] * cfg["num_hidden_layers"]
+    assert st["k_unsealed"] >= 0.9 * st["k_pages"], st
+    assert st["k_layers_on"] == 0 and st["v_layers_on"] == cfg["num_hidden_layers"], st
