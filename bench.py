@@ -401,6 +401,10 @@ def main():
         prof[nm].update(train_ms=ms, train_bytes=by)
     t_decode_all = t_ramp + dt
     steps_all, _ = eng.sync_state()
+    try:                       # sealed KV pages: how many of this run's complete pages sealed, which layers read them
+        kv_pack = eng.kv_pack_stats()
+    except Exception:          # engine without sealed pages (MTTS_KV_PACK=0)
+        kv_pack = None
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     units = torch.tensor([float(B * K * 8)], dtype=torch.float64, device=device)
@@ -479,15 +483,16 @@ def main():
         avg_ms = p["train_ms"]
         bytes_per_launch = p["train_bytes"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch from separate --pmc passes of THIS round's kernels (profiles/r02_pmc_attention.json,
-        # tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950 correction).  Measured at B=32, L~4095: only quoted for
-        # that workload, and only from the file of the round that last touched csrc/attn.hip.
+        # HBM traffic per launch from separate --pmc passes of the kernels as they are NOW (tools/pmc_summary.py; FETCH_SIZE
+        # doubled per the gfx950 correction).  Measured at B=32, L~4095: only quoted for that workload, and only from the
+        # file of the round that last touched csrc/attn.hip (r03: sealed pages, template arguments <G, fused, sealed>).
         traffic, traffic_src = None, None
-        for cand in ("r02_pmc_attention.json",):
+        sealed = bool(kv_pack and kv_pack["k_layers_on"] == cfg["num_hidden_layers"] and kv_pack["v_layers_on"] == cfg["num_hidden_layers"])
+        for cand, key in (("r03_pmc_attention.json", dom + ("<2, false, true>" if sealed else "<2, false, false>")),):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
                 if B == 32 and L == 4096 and not args.layers:
-                    traffic = pmc[dom + "<2, false>"]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
+                    traffic = pmc[key]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
                     traffic_src = "profiles/" + cand
                     break
             except Exception:
@@ -517,7 +522,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": 4 * cfg["num_hidden_layers"],
-                         "how": "train of back-to-back launches at the end-of-run KV length, 2 HIP events on the launch stream"},
+                         "how": "train of back-to-back launches at the end-of-run KV length, 2 HIP events on the launch stream; "
+                                "`achieved` counts the ALGORITHMIC bytes (the bf16 K or V of every cached token, SURVEY 8d); the kernel "
+                                "reads complete pages in their sealed 13-bit form (kv_pack), so `traffic` is below them"},
+            "kv_pack": kv_pack,
             "kernels": {k: {"avg_ms": v["ms"] / max(v["launches"], 1), "launches": v["launches"], "train_ms": v.get("train_ms"),
                             "GBps": (v["bytes"] / max(v["launches"], 1)) / (v["ms"] / max(v["launches"], 1) * 1e-3) / 1e9
                             if v["ms"] > 0 and v["bytes"] else None} for k, v in prof.items()},

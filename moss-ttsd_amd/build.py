@@ -12,6 +12,7 @@ SRC = ["gemm.hip", "layer.hip", "attn.hip", "sampler.hip", "f32path.hip", "engin
 OUT = os.path.join(HERE, "lib", "libmtts.so")
 OBJ = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS += os.environ.get("MTTS_BUILD_FLAGS", "").split()          # tuning experiments (-DNAME=value), with --force
 
 
 def _newer(target, deps):

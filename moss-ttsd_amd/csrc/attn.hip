@@ -12,6 +12,16 @@
 //
 // HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.
 #include "common.h"
+#include <cstdlib>
+// waves per SIMD the sealed-page kernels are compiled for (register budget 512 / N); 0 = the compiler's choice
+#ifndef MTTS_PK_WAVES
+#define MTTS_PK_WAVES 0
+#endif
+#if MTTS_PK_WAVES
+#define PK_OCC(PK) __attribute__((amdgpu_waves_per_eu((PK) ? MTTS_PK_WAVES : 1, (PK) ? MTTS_PK_WAVES : 8)))
+#else
+#define PK_OCC(PK)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Sealed pages (common.h: MTTS_PKU).  A bf16 value is [sign | exponent 8 | mantissa 7]; over the 128 values one lane
@@ -223,7 +233,7 @@ __device__ __forceinline__ void fuse_norm_rope(const QkvFuse& f, const FuseVec& 
 // block whose pages hold position `pos` also produces the new K row, writes it to the cache and uses it from LDS.
 // PK: pages before the one that receives this step's token are complete, hence sealed: 13 loads per lane instead of 16.
 template <int G, bool FUSED, bool PK>
-__global__ __launch_bounds__(256) void attn_scores_kernel(
+__global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
     const uint16_t* __restrict__ qbuf, u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
     const RowMeta* __restrict__ meta, uint16_t* __restrict__ scores, float* __restrict__ stats, int max_pages,
     int total_pages, int nq, int nkv, float scale, QkvFuse f, const u32x4_t* __restrict__ kpack) {
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
 // FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
 // writes it to the cache and patches it into the page it has just loaded.
 template <int G, bool FUSED, bool PK>
-__global__ __launch_bounds__(PV_WAVES * 64) void attn_pv_kernel(
+__global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
     int max_pages, int total_pages, int nchunks_max, int nq, int nkv, QkvFuse f, const u32x4_t* __restrict__ vpack) {
