@@ -127,6 +127,29 @@ __global__ __launch_bounds__(128) void kv_seal_rows_kernel(const u32x4_t* __rest
                                (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
     seal_count(fit, cnt, layer, wave, lane);
 }
+// The same for a prefill pass (thousands of rows, one in 64 completes a page): a block looks at 64 rows and seals what
+// it finds.  grid = (ceil(R / 64), nkv, L), block 128.
+__global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
+                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack,
+                                                           const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, int R,
+                                                           int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
+                                                           unsigned long long* __restrict__ cnt) {
+    const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 64 + lane;
+    RowMeta m{-1, 0, 0, 0};
+    if (r < R) m = meta[r];
+    unsigned long long todo = __ballot(m.seq >= 0 && (m.pos & 63) == 63);
+    while (todo) {
+        const int i = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int seq = __shfl(m.seq, i, 64), pos = __shfl(m.pos, i, 64);
+        const int page = page_table[(size_t)seq * max_pages + (pos >> 6)];
+        const size_t pi = (size_t)kvh * total_pages + page;
+        const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                   (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+        seal_count(fit, cnt, layer, wave, lane);
+    }
+}
 // Every physical page (measurement hook: after the caches were filled behind the engine's back).  grid = (pages, nkv, L)
 __global__ __launch_bounds__(128) void kv_seal_all_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack, int total_pages,
@@ -172,6 +195,11 @@ void launch_kv_pack_count(const void* kpack, const void* vpack, const int32_t* p
 void launch_kv_seal_rows(const void* kcache, const void* vcache, void* kpack, void* vpack, const int32_t* page_table,
                          const RowMeta* meta, int R, int max_pages, int total_pages, int nkv, int L, unsigned long long* cnt, hipStream_t st) {
     const size_t raw_layer = (size_t)total_pages * nkv * (MTTS_PAGE * MTTS_HD / 8), pk_layer = (size_t)total_pages * nkv * (MTTS_PKU * 64);
+    if (R > MTTS_RCAP) {                               // a prefill pass
+        hipLaunchKernelGGL(kv_seal_scan_kernel, dim3((R + 63) / 64, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
+                           (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, R, max_pages, total_pages, raw_layer, pk_layer, cnt);
+        return;
+    }
     hipLaunchKernelGGL(kv_seal_rows_kernel, dim3(R, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
                        (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, max_pages, total_pages, raw_layer, pk_layer, cnt);
 }
@@ -247,7 +275,8 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
     if ((int)blockIdx.x * 4 >= npages) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pg = blockIdx.x * 4 + wave;
-    // K loads first (they only need the page index); q is staged through LDS while they fly
+    // K loads first (they only need the page index); q is staged through LDS while they fly (requesting q before the
+    // page instead was measured in round 3: no difference)
     u32x4_t kv[16];
     const int own_pg = m.pos >> 6;                    // page that receives this step's token
     bool packed = PK && pg < own_pg;                  // (wave-uniform)
@@ -364,7 +393,10 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
 // d = 4*(l&31).. of token pair 2*it + (l>>5): one contiguous KiB per wave instruction.
 // FUSED (decode rows): the wave whose pages hold position `pos` reduces the new V row from the qkv GEMM's slabs,
 // writes it to the cache and patches it into the page it has just loaded.
-template <int G, bool FUSED, bool PK>
+// SF: the (max, sumexp) pairs of the row's first 64 pages are requested BEFORE the V page (loads return in order: behind
+// 13-16 KiB of page they would arrive last, and the statistics would be reduced after the page has landed instead of
+// while it is in flight).
+template <int G, bool FUSED, bool PK, bool SF>
 __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
     const uint16_t* __restrict__ scores, const float* __restrict__ stats, u32x4_t* __restrict__ vcache,
     const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, float* __restrict__ opart,
@@ -381,13 +413,29 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Lmax = max_pages * MTTS_PAGE;
     const int sub = lane >> 5, dl = lane & 31;
+    float2 s0[G];
+    if (SF) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float* st = stats + ((size_t)r * nq + kvh * G + g) * max_pages * 2;
+            s0[g] = lane < npages ? *(const float2*)(st + 2 * lane) : float2{-INFINITY, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // V loads of this wave's first page go out before the softmax statistics are reduced
     u32x4_t vv[16];
     int pg = chunk * ATT_PB + wave * (ATT_PB / PV_WAVES);
     const int own_pg = m.pos >> 6;
     bool packed = false;
     const u32x4_t* vp = nullptr;
+    uint16_t sraw[G];                                 // this lane's token of the page: its score per head
     auto load_page = [&]() {                          // complete pages are sealed: 13 loads per lane instead of 16
+        if (SF) {                                     // the page's scores first: two bytes that would otherwise queue behind the page
+            const int tok = pg * MTTS_PAGE + lane;
+#pragma unroll
+            for (int g = 0; g < G; ++g) sraw[g] = tok < len ? scores[((size_t)r * nq + kvh * G + g) * Lmax + tok] : (uint16_t)0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int page = page_table[(size_t)m.seq * max_pages + pg];
         vp = vcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
         packed = PK && pg < own_pg;
@@ -419,10 +467,12 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
     for (int g = 0; g < G; ++g) {
         const float* st = stats + ((size_t)r * nq + kvh * G + g) * max_pages * 2;
         float mx = -INFINITY;
-        for (int p = lane; p < npages; p += 64) mx = fmaxf(mx, st[2 * p]);
+        if (SF) mx = fmaxf(mx, s0[g].x);
+        for (int p = lane + (SF ? 64 : 0); p < npages; p += 64) mx = fmaxf(mx, st[2 * p]);
         mx = wave_max(mx);
         float sm = 0.f;
-        for (int p = lane; p < npages; p += 64) sm += st[2 * p + 1] * expf(st[2 * p] - mx);
+        if (SF && lane < npages) sm += s0[g].y * expf(s0[g].x - mx);
+        for (int p = lane + (SF ? 64 : 0); p < npages; p += 64) sm += st[2 * p + 1] * expf(st[2 * p] - mx);
         sm = wave_sum(sm);
         M[g] = mx;
         S[g] = sm;
@@ -462,7 +512,7 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
             for (int g = 0; g < G; ++g) {
                 float p = 0.f;
                 if (tok < len) {
-                    float s = bf2f(scores[((size_t)r * nq + kvh * G + g) * Lmax + tok]);
+                    float s = bf2f(SF ? sraw[g] : scores[((size_t)r * nq + kvh * G + g) * Lmax + tok]);
                     p = expf(s - M[g]) / S[g];
                 }
                 pbuf[wave][g][lane] = f2bf(p);
@@ -746,6 +796,14 @@ __global__ __launch_bounds__(256) void attn_prefill_pv_kernel(
     }
 }
 
+static bool pv_stats_first() {          // MTTS_PV_STATS_FIRST=0: the round-1 order (page loads first)
+    static int v = -1;
+    if (v < 0) {
+        const char* g = getenv("MTTS_PV_STATS_FIRST");
+        v = (g && atoi(g) == 0) ? 0 : 1;
+    }
+    return v != 0;
+}
 template <int G>
 static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const int32_t* page_table,
                           const RowMeta* meta, void* scores, float* stats, float* opart, void* out_packed, int R,
@@ -775,9 +833,14 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
 #define MTTS_SC(FU, PK)                                                                                                  \
     hipLaunchKernelGGL((attn_scores_kernel<G, FU, PK>), ga, dim3(256), 0, st, (const uint16_t*)qbuf, (u32x4_t*)kcache, \
                        page_table, meta, (uint16_t*)scores, stats, max_pages, total_pages, nq, nkv, scale, f, kpk)
-#define MTTS_PV(FU, PK)                                                                                                         \
-    hipLaunchKernelGGL((attn_pv_kernel<G, FU, PK>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats, \
+#define MTTS_PV2(FU, PK, SF)                                                                                                        \
+    hipLaunchKernelGGL((attn_pv_kernel<G, FU, PK, SF>), gb, dim3(PV_WAVES * 64), 0, st, (const uint16_t*)scores, (const float*)stats, \
                        (u32x4_t*)vcache, page_table, meta, opart, max_pages, total_pages, nchunks_max, nq, nkv, f, vpk)
+#define MTTS_PV(FU, PK)                        \
+    do {                                       \
+        if (pv_stats_first()) MTTS_PV2(FU, PK, true); \
+        else MTTS_PV2(FU, PK, false);          \
+    } while (0)
     if (phase == 0 || phase == 1) {
         dim3 ga((pages_bound + 3) / 4, nkv, R);
         if (fuse) { if (kpk) MTTS_SC(true, true); else MTTS_SC(true, false); }
@@ -790,6 +853,7 @@ static void launch_attn_g(const void* qbuf, void* kcache, void* vcache, const in
     }
 #undef MTTS_SC
 #undef MTTS_PV
+#undef MTTS_PV2
     if (phase == 0 || phase == 3)
         hipLaunchKernelGGL(attn_combine_kernel, dim3(R, (nq + 3) / 4), dim3(512), 0, st, (const float*)opart, meta,
                            (uint16_t*)out_packed, nchunks_max, nq, ATT_PB);
