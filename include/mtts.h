@@ -221,9 +221,14 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
 /* The sealed page format on its own: dev_pages = npages x 16 KiB (a page as the cache holds it: [16 units][64 lanes][16 B]),
  * dev_sealed = npages x 13 KiB ([13 units][64 lanes][16 B]: units 0-7 the low bytes of the lane's 128 values in order,
  * 8-11 one code nibble per value (byte 4j+k: low nibble = value 8j+k, high nibble = value 8j+4+k; code = sign << 3 | index),
- * unit 12 = 8 dictionary bytes ((bf16 >> 8) & 0x7f, ascending), 4 zero bytes, a 32-bit flag: != 0 = the lane did not fit
- * and the rest of its sealed data is undefined).  Lossless: value = sign << 15 | dictionary[index] << 8 | low byte. */
-int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, void* stream);
+ * unit 12 = 8 dictionary bytes ((bf16 >> 8) & 0x7f, ascending), a 32-bit spare, a 32-bit flag: != 0 = the lane did not fit
+ * and the rest of its sealed data is undefined).  Lossless: value = sign << 15 | dictionary[index] << 8 | low byte.
+ * as_k = 0: the values as they are (V pages).  as_k = 1 (K pages: lane = token, value i = dim i): dim d is first divided
+ * by 2^s[d], s[d] = (rounded mean of the non-zero exponent fields of dim d over the page's 64 tokens) - 125 (0 for an
+ * all-zero dim; clamped to -127..127), lane l
+ * keeps s[2l], s[2l+1] as int8 in the low 16 bits of its spare; k = stored value x 2^s[d] exactly (a lane with a denormal,
+ * inf / NaN or an exponent that would leave 1..254 is flagged instead). */
+int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, int32_t as_k, void* stream);
 /* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
 int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,
                       const void* dev_history_bitmap, const MttsSamplerCfg* cfg,

@@ -45,11 +45,8 @@ __device__ __forceinline__ void pk_unit(const u32x4_t* pk, int j, uint32_t w[4])
     w[3] = __builtin_amdgcn_perm(HB, L1, 0x07030602u);
 }
 
-// One lane's share of a page (16 units of 16 B, 64 lanes apart) -> its sealed form (13 units).
-__device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
-    u32x4_t v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = raw[j * 64];
+// One lane's share of a page (16 units of 16 B in registers) -> its sealed form (13 units); `spare` = third dword of unit 12.
+__device__ bool seal_encode(const u32x4_t (&v)[16], u32x4_t* __restrict__ pk, uint32_t spare, bool unfit) {
     unsigned long long b0 = 0ull, b1 = 0ull;                  // which of the 128 possible high bytes occur
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -62,8 +59,8 @@ __device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__
                 else b0 |= 1ull << e;
             }
     const int n0 = __popcll(b0), n = n0 + __popcll(b1);
-    if (n > 8) {                                              // does not fit: readers take the bf16 page
-        pk[12 * 64] = u32x4_t{0u, 0u, 0u, 1u};
+    if (n > 8 || unfit) {                                     // does not fit: readers take the bf16 page
+        pk[12 * 64] = u32x4_t{0u, 0u, spare, 1u};
         return false;
     }
     unsigned long long dict = 0ull;                           // entry i = the i-th smallest high byte present
@@ -102,8 +99,77 @@ __device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__
     for (int u = 0; u < 8; ++u) pk[u * 64] = u32x4_t{lowp[4 * u], lowp[4 * u + 1], lowp[4 * u + 2], lowp[4 * u + 3]};
 #pragma unroll
     for (int u = 0; u < 4; ++u) pk[(8 + u) * 64] = u32x4_t{nib[4 * u], nib[4 * u + 1], nib[4 * u + 2], nib[4 * u + 3]};
-    pk[12 * 64] = u32x4_t{(uint32_t)dict, (uint32_t)(dict >> 32), 0u, 0u};
+    pk[12 * 64] = u32x4_t{(uint32_t)dict, (uint32_t)(dict >> 32), spare, 0u};
     return true;
+}
+// V pages (and the format hook): the lane's values as they are.
+__device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
+    u32x4_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = raw[j * 64];
+    return seal_encode(v, pk, 0u, false);
+}
+// K pages: a lane is a token's 128 dims, and what spreads their magnitudes is the dim (k_norm's weight, the RoPE
+// frequency), not the token.  So each dim is first divided by a power of two chosen from the page itself (the mean
+// exponent of that dim over the 64 tokens goes to 125), the shifts are kept in the page (lane l: dims 2l, 2l+1, in the
+// spare dword of unit 12) and the READER multiplies q by the same powers of two: k 2^-s . q 2^s is the same fp32 product,
+// bit for bit, as long as every rescaled exponent stays normal -- a lane (or a q) where it would not is flagged and
+// the page is read as bf16.  `lds` = 8 KiB + 128 B of this wave's own.
+__device__ bool seal_lane_k(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk, uint8_t* __restrict__ lds, int lane) {
+    u32x4_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = raw[j * 64];
+    __builtin_amdgcn_wave_barrier();                          // (a previous page's reads of `lds` are done: same wave, in order)
+    uint32_t* row = (uint32_t*)(lds + lane * 128);            // this token's 128 exponents, dim order
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            const uint32_t a = u4c(v[j], c), b = u4c(v[j], c + 1);
+            row[2 * j + (c >> 1)] = ((a >> 7) & 0xffu) | (((a >> 23) & 0xffu) << 8) | (((b >> 7) & 0xffu) << 16) | (((b >> 23) & 0xffu) << 24);
+        }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t a0 = 0u, a1 = 0u, n0 = 0u, n1 = 0u;              // dims 2 lane, 2 lane + 1: sum / count of the tokens' non-zero exponent fields
+    for (int t = 0; t < 64; ++t) {
+        const uint32_t e = *(const uint16_t*)(lds + t * 128 + 2 * lane);
+        a0 += e & 0xffu; n0 += (e & 0xffu) ? 1u : 0u;
+        a1 += e >> 8; n1 += (e >> 8) ? 1u : 0u;
+    }
+    // the dim's MEAN exponent goes to 125 (the mean, not the maximum: one outlying token -- the first of a dialogue --
+    // must not push the dim's other 63 values away from the other dims')
+    const int s0 = n0 ? min(max((int)((a0 + n0 / 2) / n0) - 125, -127), 127) : 0;
+    const int s1 = n1 ? min(max((int)((a1 + n1 / 2) / n1) - 125, -127), 127) : 0;
+    int8_t* sv = (int8_t*)(lds + 8192);
+    sv[2 * lane] = (int8_t)s0;
+    sv[2 * lane + 1] = (int8_t)s1;
+    __builtin_amdgcn_wave_barrier();
+    bool unfit = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t sh = *(const uint16_t*)(sv + 8 * j + 2 * c);
+            uint32_t out = 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t b = (w[c] >> (16 * h)) & 0xffffu;
+                const int sft = (int)(int8_t)((sh >> (8 * h)) & 0xffu);
+                const int e = (int)((b >> 7) & 0xffu);
+                if (e == 0) {
+                    if ((b & 0x7fu) && sft) unfit = true;     // a denormal cannot be rescaled exactly
+                } else {
+                    const int e2 = e - sft;
+                    if (e == 255 ? sft != 0 : (e2 < 1 || e2 > 254)) unfit = true;
+                    else b = (b - ((uint32_t)sft << 7)) & 0xffffu;
+                }
+                out |= b << (16 * h);
+            }
+            w[c] = out;
+        }
+        v[j] = u32x4_t{w[0], w[1], w[2], w[3]};
+    }
+    return seal_encode(v, pk, ((uint32_t)s0 & 0xffu) | (((uint32_t)s1 & 0xffu) << 8), unfit);
 }
 // counters per layer: {K pages sealed, K pages with a lane that did not fit, the same for V} (the engine's read policy)
 __device__ __forceinline__ void seal_count(bool fit, unsigned long long* __restrict__ cnt, int layer, int wave, int lane) {
@@ -118,13 +184,16 @@ __global__ __launch_bounds__(128) void kv_seal_rows_kernel(const u32x4_t* __rest
                                                            const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta,
                                                            int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
                                                            unsigned long long* __restrict__ cnt) {
+    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
     const RowMeta m = meta[blockIdx.x];
     if (m.seq < 0 || (m.pos & 63) != 63) return;
     const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int page = page_table[(size_t)m.seq * max_pages + (m.pos >> 6)];
     const size_t pi = (size_t)kvh * total_pages + page;
-    const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                               (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+    const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                      vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
+                          : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                        kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
     seal_count(fit, cnt, layer, wave, lane);
 }
 // The same for a prefill pass (thousands of rows, one in 64 completes a page): a block looks at 64 rows and seals what
@@ -134,6 +203,7 @@ __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __rest
                                                            const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, int R,
                                                            int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
                                                            unsigned long long* __restrict__ cnt) {
+    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
     const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 64 + lane;
     RowMeta m{-1, 0, 0, 0};
@@ -145,8 +215,10 @@ __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __rest
         const int seq = __shfl(m.seq, i, 64), pos = __shfl(m.pos, i, 64);
         const int page = page_table[(size_t)seq * max_pages + (pos >> 6)];
         const size_t pi = (size_t)kvh * total_pages + page;
-        const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                                   (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+        const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                          vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
+                              : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                            kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
         seal_count(fit, cnt, layer, wave, lane);
     }
 }
@@ -154,18 +226,25 @@ __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __rest
 __global__ __launch_bounds__(128) void kv_seal_all_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack, int total_pages,
                                                           size_t raw_layer, size_t pk_layer, unsigned long long* __restrict__ cnt) {
+    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
     const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t pi = (size_t)kvh * total_pages + blockIdx.x;
-    const bool fit = seal_lane((wave ? vcache : kcache) + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                               (wave ? vpack : kpack) + layer * pk_layer + pi * (MTTS_PKU * 64) + lane);
+    const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                      vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
+                          : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                        kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
     seal_count(fit, cnt, layer, wave, lane);
 }
 // Test hook: `npages` pages in a row (bf16 form, 16 KiB each) -> their sealed forms (13 KiB each).  grid = pages, block 64
-__global__ __launch_bounds__(64) void kv_seal_pages_kernel(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
-    seal_lane(raw + (size_t)blockIdx.x * (MTTS_PAGE * MTTS_HD / 8) + threadIdx.x, pk + (size_t)blockIdx.x * (MTTS_PKU * 64) + threadIdx.x);
+__global__ __launch_bounds__(64) void kv_seal_pages_kernel(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk, int as_k) {
+    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
+    const u32x4_t* src = raw + (size_t)blockIdx.x * (MTTS_PAGE * MTTS_HD / 8) + threadIdx.x;
+    u32x4_t* dst = pk + (size_t)blockIdx.x * (MTTS_PKU * 64) + threadIdx.x;
+    if (as_k) seal_lane_k(src, dst, klds, threadIdx.x);
+    else seal_lane(src, dst);
 }
-void launch_kv_seal_pages(const void* raw, void* pk, int npages, hipStream_t st) {
-    hipLaunchKernelGGL(kv_seal_pages_kernel, dim3(npages), dim3(64), 0, st, (const u32x4_t*)raw, (u32x4_t*)pk);
+void launch_kv_seal_pages(const void* raw, void* pk, int npages, int as_k, hipStream_t st) {
+    hipLaunchKernelGGL(kv_seal_pages_kernel, dim3(npages), dim3(64), 0, st, (const u32x4_t*)raw, (u32x4_t*)pk, as_k);
 }
 // Debug hook: how many of the complete pages of the live sequences are sealed / had a lane that did not fit.
 // grid = (slots, nkv, L), block 64; out = {K pages, K pages not sealed, V pages, V pages not sealed}
@@ -267,6 +346,7 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
     int total_pages, int nq, int nkv, float scale, QkvFuse f, const u32x4_t* __restrict__ kpack) {
     __shared__ __attribute__((aligned(16))) uint32_t qs[G][MTTS_HD / 2];   // bf16 pairs, as stored
     __shared__ __attribute__((aligned(16))) uint16_t knew[MTTS_HD];
+    __shared__ __attribute__((aligned(16))) uint32_t qw[PK ? 4 : 1][G][MTTS_HD / 2];   // q times the sealed page's per-dim powers of two
     const int r = blockIdx.z, kvh = blockIdx.y;
     const RowMeta m = meta[r];
     if (m.seq < 0) return;
@@ -326,7 +406,29 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) kv[j] = *(const u32x4_t*)&knew[8 * j];
     }
-    if (PK && packed && __any(kv[12].w != 0u)) {      // a row of this page did not fit the sealed form: take the bf16 page
+    bool qok = true;
+    if (PK && packed) {                               // the page's K is k 2^-s per dim: this wave's q becomes q 2^s (exact, or flagged)
+        const uint32_t sh = kv[12].z;                 // shifts of dims 2 lane, 2 lane + 1
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t qd = qs[g][lane];
+            uint32_t out = 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t b = (qd >> (16 * h)) & 0xffffu;
+                const int sft = (int)(int8_t)((sh >> (8 * h)) & 0xffu);
+                if ((b & 0x7fffu) && sft) {
+                    const int e = (int)((b >> 7) & 0xffu), e2 = e + sft;
+                    if (e == 0 || e == 255 || e2 < 1 || e2 > 254) qok = false;
+                    else b = (b + ((uint32_t)sft << 7)) & 0xffffu;
+                }
+                out |= b << (16 * h);
+            }
+            qw[wave][g][lane] = out;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (PK && packed && __any(kv[12].w != 0u || !qok)) {      // a row of this page (or this q) did not fit: take the bf16 page
         packed = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
@@ -343,7 +445,7 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
             pk_unit(kv, j, w);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
+                const u32x4_t q = *(const u32x4_t*)&qw[PK ? wave : 0][g][4 * j];
                 acc[g] = dot2bf(w[0], q.x, acc[g]);
                 acc[g] = dot2bf(w[1], q.y, acc[g]);
                 acc[g] = dot2bf(w[2], q.z, acc[g]);

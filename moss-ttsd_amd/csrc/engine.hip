@@ -54,7 +54,7 @@ void launch_kv_seal_rows(const void* kcache, const void* vcache, void* kpack, vo
                          const RowMeta* meta, int R, int max_pages, int total_pages, int nkv, int L, unsigned long long* cnt, hipStream_t st);
 void launch_kv_seal_all(const void* kcache, const void* vcache, void* kpack, void* vpack, int total_pages, int nkv, int L,
                         unsigned long long* cnt, hipStream_t st);
-void launch_kv_seal_pages(const void* raw, void* pk, int npages, hipStream_t st);
+void launch_kv_seal_pages(const void* raw, void* pk, int npages, int as_k, hipStream_t st);
 void launch_kv_pack_count(const void* kpack, const void* vpack, const int32_t* page_table, const int32_t* complete, int B, int max_pages,
                           int total_pages, int nkv, int L, unsigned long long* out, hipStream_t st);
 struct SeqState { int32_t nas, unfinished, kv_len, step, base_length, max_length, row_id, active; uint64_t seed; };
@@ -1694,9 +1694,9 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
 }
 
 // Test hook for the sealed page format (attn.hip: seal_lane): `npages` bf16 pages of 16 KiB -> sealed pages of 13 KiB.
-extern "C" int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, void* stream) {
+extern "C" int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, int32_t as_k, void* stream) {
     if (!dev_pages || !dev_sealed || npages < 1) return fail(MTTS_EINVAL, "kv_seal: bad argument");
-    launch_kv_seal_pages(dev_pages, dev_sealed, npages, S(stream));
+    launch_kv_seal_pages(dev_pages, dev_sealed, npages, as_k, S(stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(S(stream)));
     return MTTS_OK;

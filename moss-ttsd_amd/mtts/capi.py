@@ -79,7 +79,7 @@ _SIGS = {
                                       C.POINTER(C.c_int64)]),
     "mtts_debug_set_kv_len": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mtts_debug_kv_pack_stats": (C.c_int32, [C.c_void_p, C.c_void_p]),
-    "mtts_k_kv_seal": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mtts_k_kv_seal": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "mtts_k_attn_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "mtts_k_gemm_bench": (C.c_int32, [C.c_int32] * 7 + [C.POINTER(C.c_float)]),
     "mtts_k_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -35,13 +35,18 @@ def _decode_sealed(sealed):
     return ((code.astype(np.uint16) >> 3) << 15) | (hi << 8) | low, flag
 
 
-def _seal(pages_u16):
+def _k_shifts(sealed):
+    """The per-dim shifts a K page carries: lane l keeps s[2l], s[2l+1] as int8 in its spare -> int [pages, 128]."""
+    return sealed[:, 12, :, 8:10].copy().view(np.int8).reshape(sealed.shape[0], 128).astype(np.int32)
+
+
+def _seal(pages_u16, as_k=0):
     """uint16 [pages, 64 lanes, 128 values] (lane order) -> sealed uint8 [pages, 13, 64, 16] through the HIP kernel."""
     P = pages_u16.shape[0]
     raw = pages_u16.reshape(P, 64, 16, 8).transpose(0, 2, 1, 3)                    # [page][unit][lane][8 halves]
     t = torch.from_numpy(np.ascontiguousarray(raw).view(np.int16)).cuda()
     out = torch.zeros(P, 13, 64, 16, dtype=torch.uint8, device="cuda")
-    capi.check(capi.lib().mtts_k_kv_seal(t.data_ptr(), P, out.data_ptr(), None))
+    capi.check(capi.lib().mtts_k_kv_seal(t.data_ptr(), P, out.data_ptr(), int(as_k), None))
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -78,6 +83,35 @@ def test_sealed_page_format_is_lossless_and_flags_what_does_not_fit():
         assert list(s[pg, 12, ln, :len(want)]) == list(want)
 
 
+def test_sealed_k_pages_rescale_each_dim_by_a_power_of_two_exactly():
+    """K pages (lane = token, value = dim): dims whose scales differ by up to 2^24 (a k_norm weight would do that) still
+    seal, because each dim is divided by a power of two kept in the page; stored value x 2^s[d] is the original, bit for bit."""
+    rng = np.random.default_rng(9)
+    P = 8
+    x = rng.standard_normal((P, 64, 128)).astype(np.float32)
+    x *= (2.0 ** rng.integers(-12, 13, (P, 1, 128))).astype(np.float32)
+    x[1, :, 5] = 0.0                                        # an all-zero dim: shift 0
+    x[2, ::3, 7] = 0.0                                      # zeros inside a scaled dim stay zeros
+    v = _bf16_bits(x)
+    v[3, 10, 20] = 0x0003                                   # a denormal in a rescaled dim: that lane cannot be exact
+    v[4, 11, 21] = 0x7f80                                   # +inf likewise
+    v[5, :, 30] = _bf16_bits(np.full(64, 2.0 ** -100, np.float32))
+    v[5, 7, 30] = _bf16_bits(np.array([2.0 ** 100], np.float32))[0]    # one dim spanning 200 binades: the outlying token does not fit
+    sealed = _seal(v, as_k=1)
+    got, flag = _decode_sealed(sealed)
+    sh = _k_shifts(sealed)                                  # [P, 128]
+    e = ((v >> 7) & 0xff).astype(np.int64)
+    cnt, tot = (e > 0).sum(axis=1), e.sum(axis=1)
+    assert np.array_equal(sh, np.where(cnt > 0, np.clip((tot + cnt // 2) // np.maximum(cnt, 1) - 125, -127, 127), 0))
+    assert flag[3, 10] == 1 and flag[4, 11] == 1 and flag[5].sum() == 1 and flag[5, 7] == 1
+    fits = flag == 0
+    assert fits[[0, 1, 2, 6, 7]].mean() > 0.99              # the 24-binade spread between dims is gone
+    nz = (got & 0x7fff) != 0
+    back = np.where(nz, (got.astype(np.int32) + (sh[:, None, :] << 7)) & 0xffff, got).astype(np.uint16)
+    assert np.array_equal(back[fits], v[fits])
+    assert (_seal(v, as_k=0)[:, 12, :, 12:16].view(np.uint32)[..., 0] != 0).mean() > 0.9    # without the rescale nothing fits
+
+
 @pytest.mark.parametrize("nq,nkv", [(4, 2), (8, 2), (4, 4)])
 def test_decode_attention_on_sealed_pages_equals_bf16_pages_bit_for_bit(monkeypatch, nq, nkv):
     """The three decode launches over a shuffled page table, ragged lengths, with rows that seal and rows that do not
@@ -92,6 +126,8 @@ def test_decode_attention_on_sealed_pages_equals_bf16_pages_bit_for_bit(monkeypa
     K[0, 100:140] *= (2.0 ** rng.integers(-40, 1, (40, nkv, 128))).astype(np.float32)      # tokens whose K row cannot seal
     V[4, 200:300, :, 8:12] *= (2.0 ** rng.integers(-40, 1, (100, nkv, 4))).astype(np.float32)   # a V lane that cannot
     K[1:, :, :, 3] = 0.0
+    K[5] *= (2.0 ** rng.integers(-12, 13, (1, nkv, 128))).astype(np.float32)               # dims on very different scales: seals (rescaled)
+    q[2] *= 2.0 ** 60                                                                         # a q the rescale cannot take everywhere: bf16 pages
     K, V = ao.round_bf16(K), ao.round_bf16(V)
     pages = (Lmax + 63) // 64
     table = rng.permutation(R * pages).astype(np.int32).reshape(R, pages)
@@ -145,19 +181,25 @@ def test_engine_with_sealed_pages_equals_engine_without_and_pages_do_seal(monkey
     assert st["k_unsealed"] <= 0.05 * st["k_pages"] and st["v_unsealed"] <= 0.05 * st["v_pages"], st
 
 
-def test_read_policy_turns_a_layer_back_to_bf16_pages_when_its_k_rows_do_not_seal(monkeypatch):
-    """k_norm weights spread over 24 binades: a K row then holds more than 8 distinct exponent pairs and no K page seals.
-    Results stay those of the bf16 pages; after the first host sync that has seen 16 pages the engine stops reading the
-    sealed K pages of those layers (V keeps sealing and keeps its sealed reads)."""
+def test_k_seals_under_any_k_norm_spread_and_the_read_policy_drops_v_when_v_does_not(monkeypatch):
+    """k_norm weights spread over 24 binades (the same for the two dims RoPE rotates into each other: a ratio between
+    THOSE makes a dim sweep through all the binades in between as the angle turns, which no per-dim scale can undo):
+    a K row then holds far more than 8 distinct exponent pairs, but the sealer
+    rescales each dim by a power of two (and the score kernel q by the same), so K still seals.  v_proj rows scaled the
+    same way: a V lane (4 neighbouring dims x 32 tokens) cannot seal; after the first host sync that has seen 16 pages the
+    engine stops reading the sealed V pages of those layers.  Results stay those of the bf16 pages throughout."""
     from mtts.engine import Engine
     cfg = synth.tiny()
     w = synth.synth_weights(cfg, 78, emb_row_sigma=0.6, speech_boost=5.0)
     rng = np.random.default_rng(4)
     kn = [k for k in w if k.endswith("k_norm.weight")]
-    assert len(kn) == cfg["num_hidden_layers"]
+    vp = [k for k in w if k.endswith("v_proj.weight")]
+    assert len(kn) == cfg["num_hidden_layers"] == len(vp)
     for k in kn:
-        scale = (2.0 ** rng.integers(-12, 13, w[k].shape)).astype(np.float32)
-        w[k] = (w[k] * scale).astype(np.float32)                  # powers of two: still exact bf16 values
+        sc = np.tile(2.0 ** rng.integers(-12, 13, 64), 2).astype(np.float32)   # RoPE partners (d, d + 64) share a scale; powers of two: exact bf16
+        w[k] = (w[k] * sc).astype(np.float32)
+    for k in vp:
+        w[k] = (w[k] * (2.0 ** (-8.0 * (np.arange(w[k].shape[0]) % 4)))[:, None].astype(np.float32)).astype(np.float32)   # a lane's 4 dims: 1, 2^-8, 2^-16, 2^-24
     B, T = 2, 700
     ids = np.full((B, T, 8), 1024, dtype=np.int64)
     ids[:, :, 0] = rng.integers(0, cfg["vocab_size"] - 10, (B, T))
@@ -174,6 +216,7 @@ def test_read_policy_turns_a_layer_back_to_bf16_pages_when_its_k_rows_do_not_sea
     assert np.array_equal(res["0"][0], res["1"][0])
     assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2])
     st = res["1"][3]
-    assert st["k_pages"] >= 2 * 10 * cfg["num_key_value_heads"] * cfg["num_hidden_layers"]
-    assert st["k_unsealed"] >= 0.9 * st["k_pages"], st
-    assert st["k_layers_on"] == 0 and st["v_layers_on"] == cfg["num_hidden_layers"], st
+    L = cfg["num_hidden_layers"]
+    assert st["k_pages"] >= 2 * 10 * cfg["num_key_value_heads"] * L
+    assert st["k_unsealed"] <= 0.1 * st["k_pages"] and st["k_layers_on"] == L, st
+    assert st["v_unsealed"] >= 0.9 * st["v_pages"] and st["v_layers_on"] == 0, st
