@@ -215,6 +215,7 @@ struct MttsEngine {
     // counts per layer {K sealed, K not, V sealed, V not}, mtts_sync_state looks at the counts (MTTS_KV_PACK=2: no policy)
     unsigned long long *d_seal_cnt = nullptr, *h_seal_cnt = nullptr;
     std::vector<char> pack_k_on, pack_v_on;
+    int pack_min_work = 512;            // sealed reads from this many rows x KV pages up (MTTS_KV_PACK_MIN)
     int fuse_qkv_max = 1024;            // decode: q/k/v epilogue inside the attention kernels while rows x KV pages <= this
     int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
@@ -404,6 +405,7 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
     if (const char* g = getenv("MTTS_GRAPHS")) e->use_graphs = atoi(g) != 0;
     if (const char* g = getenv("MTTS_FUSE_QKV_MAX")) e->fuse_qkv_max = atoi(g);
     if (const char* g = getenv("MTTS_KV_PACK")) e->kv_pack = atoi(g);
+    if (const char* g = getenv("MTTS_KV_PACK_MIN")) e->pack_min_work = atoi(g);
     if (const char* g = getenv("MTTS_PREFILL_MFMA_PAGES")) e->pf_mfma_pages = atoi(g);
     if (const char* g = getenv("MTTS_SMALL_ROWS")) e->small_rows = std::min(std::max(atoi(g), 0), SMALL_RP);
     e->H = c->hidden_size; e->I = c->intermediate_size; e->L = c->num_hidden_layers;
@@ -733,8 +735,11 @@ static int pack_policy_reset(MttsEngine* e, hipStream_t st) {
     return 0;
 }
 // this layer's sealed pools, each null where the read policy (or MTTS_KV_PACK=0) says bf16 pages
-static KvPack layer_pack(MttsEngine* e, int n) {
+static KvPack layer_pack(MttsEngine* e, int n, int pages_bound) {
     KvPack pk{nullptr, nullptr};
+    // few rows x pages: the passes are latency-bound and the unpack sits on the critical path (B=1 at 2 k: +4 %; break-even
+    // at 8 rows x 64 pages, -6 % at 16 x 64: profiles/r03_kv_pack_ab.txt)
+    if (e->B * pages_bound < e->pack_min_work) return pk;
     if (e->kpack && e->pack_k_on[n]) pk.k = (uint8_t*)e->kpack + e->pk_layer_stride * n;
     if (e->vpack && e->pack_v_on[n]) pk.v = (uint8_t*)e->vpack + e->pk_layer_stride * n;
     return pk;
@@ -764,7 +769,7 @@ static int forward_small(MttsEngine* e, const RowMeta* d_meta, int pages_bound, 
         const bool fused = e->B * pages_bound <= e->fuse_qkv_max;
         const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
                          (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
-        const KvPack pk = layer_pack(e, n);
+        const KvPack pk = layer_pack(e, n, pages_bound);
         if (!fused)
             launch_qkv_post(e->partial, e->p_qkv.ksplit, e->qkv_rows, d_meta, l.qn, l.kn, e->rope_cos, e->rope_sin, e->qbuf,
                             kc, vc, e->d_page_table, e->max_pages, e->total_pages, R, nq, nkv, eps, st);
@@ -843,7 +848,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         const int ph0 = (heads != 1 && pages_bound >= e->pf_mfma_pages) ? 10 : 0;
         // decode rows read complete pages in their sealed form; prefill rows (a page may be completed by the pass
         // itself) read the bf16 pages
-        const KvPack pk = layer_pack(e, n);
+        const KvPack pk = layer_pack(e, n, pages_bound);
         for (int phase = 1; phase <= 3; ++phase) {
             hipEvent_t ev = nullptr;
             if (phase < 3) prof_begin(e, phase == 1 ? PROF_SCORES : PROF_PV, st, &ev);
@@ -1778,7 +1783,7 @@ extern "C" int32_t mtts_k_attn_bench(MttsEngine* e, int32_t phase, int32_t iters
             const QkvFuse fz{e->partial, e->p_qkv.ksplit, e->qkv_rows, (const uint16_t*)e->layers[layer].qn,
                              (const uint16_t*)e->layers[layer].kn, (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin,
                              e->cfg.rms_norm_eps};
-            const KvPack pk = layer_pack(e, layer);
+            const KvPack pk = layer_pack(e, layer, pages_bound);
             launch_attn(e->qbuf, kc, vc, e->d_page_table, e->d_meta, e->scores, e->stats, e->opart, e->attn_p, R, pages_bound,
                         e->max_pages, e->total_pages, e->nchunks_max, e->nq, e->nkv, scale, e->B * pages_bound <= e->fuse_qkv_max ? &fz : nullptr, phase, nullptr,
                         (pk.k || pk.v) ? &pk : nullptr);
