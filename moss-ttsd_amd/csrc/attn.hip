@@ -45,6 +45,12 @@ __device__ __forceinline__ void pk_unit(const u32x4_t* pk, int j, uint32_t w[4])
     w[3] = __builtin_amdgcn_perm(HB, L1, 0x07030602u);
 }
 
+// Block barrier for data exchanged through LDS only: __syncthreads() also fences global memory, i.e. waits for every load
+// in flight (vmcnt(0)) -- exactly the page loads that should keep flying across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// i-th unit to request so that unit j's operands (low (j >> 1), nibbles 8 + (j >> 2), dictionary 12) are complete as
+// early as possible: 12, 8, 0, 1, 9, 2, 3, 10, 4, 5, 11, 6, 7
+__host__ __device__ constexpr int pk_order(int i) { return i == 0 ? 12 : (i - 1) % 3 == 0 ? 8 + (i - 1) / 3 : 2 * ((i - 1) / 3) + (i - 1) % 3 - 1; }
 // One lane's share of a page (16 units of 16 B in registers) -> its sealed form (13 units); `spare` = third dword of unit 12.
 __device__ bool seal_encode(const u32x4_t (&v)[16], u32x4_t* __restrict__ pk, uint32_t spare, bool unfit) {
     unsigned long long b0 = 0ull, b1 = 0ull;                  // which of the 128 possible high bytes occur
@@ -339,6 +345,10 @@ __device__ __forceinline__ void fuse_norm_rope(const QkvFuse& f, const FuseVec& 
 // FUSED (decode rows): q comes from the qkv GEMM's slabs (reduce, RMSNorm, RoPE done here, one head per wave), and the
 // block whose pages hold position `pos` also produces the new K row, writes it to the cache and uses it from LDS.
 // PK: pages before the one that receives this step's token are complete, hence sealed: 13 loads per lane instead of 16.
+// The kernel body exists twice, once per page form, each straight-line from its loads to its dot products: with ONE
+// body behind a join of "13 or 16 loads in flight" the compiler's wait counts collapse to "wait for everything", and the
+// point of the load order (q, then the page in the order the dot products consume it) is that the first products start
+// while the last units are still in flight.
 template <int G, bool FUSED, bool PK>
 __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
     const uint16_t* __restrict__ qbuf, u32x4_t* __restrict__ kcache, const int32_t* __restrict__ page_table,
@@ -353,62 +363,112 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
     const int len = m.pos + 1;
     const int npages = (len + MTTS_PAGE - 1) / MTTS_PAGE;
     if ((int)blockIdx.x * 4 >= npages) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int pg = blockIdx.x * 4 + wave;
-    // K loads first (they only need the page index); q is staged through LDS while they fly (requesting q before the
-    // page instead was measured in round 3: no difference)
-    u32x4_t kv[16];
     const int own_pg = m.pos >> 6;                    // page that receives this step's token
-    bool packed = PK && pg < own_pg;                  // (wave-uniform)
-    const u32x4_t* kp = nullptr;
-    if (pg < npages) {
-        const int page = page_table[(size_t)m.seq * max_pages + pg];
-        kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
-        if (packed) {
-            const u32x4_t* pp = kpack + ((size_t)kvh * total_pages + page) * (MTTS_PKU * 64) + lane;
+    const int Lmax = max_pages * MTTS_PAGE;
+    // q first (separate q/k/v epilogue): loads return in order, so behind the page q would arrive last
+    uint32_t qreg[(G * MTTS_HD / 2 + 255) / 256];
+    if (!FUSED) {
 #pragma unroll
-            for (int j = 0; j < MTTS_PKU; ++j) kv[j] = __builtin_nontemporal_load(pp + j * 64);
+        for (int i = 0; i < (G * MTTS_HD / 2 + 255) / 256; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            qreg[i] = idx < G * MTTS_HD / 2 ? ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G) * (MTTS_HD / 2) + idx] : 0u;
+        }
+    }
+    const int page = pg < npages ? page_table[(size_t)m.seq * max_pages + pg] : 0;
+    const u32x4_t* kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
+
+    // q (and, in the block that holds the step's own page, the new K row) into LDS; then the block barrier
+    auto stage_q = [&]() {
+        if (FUSED) {
+            const bool own = (own_pg >> 2) == (int)blockIdx.x;
+            for (int hh = wave; hh < G + (own ? 1 : 0); hh += 4) {
+                const bool isk = hh == G;
+                float a, b, o1, o2;
+                const FuseVec fv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
+                fuse_reduce(f, r, (isk ? nq + kvh : kvh * G + hh) * MTTS_HD, lane, a, b);
+                fuse_norm_rope(f, fv, a, b, o1, o2);
+                if (!isk) {
+                    ((uint16_t*)qs[hh])[lane] = f2bf(o1);
+                    ((uint16_t*)qs[hh])[lane + 64] = f2bf(o2);
+                } else {
+                    knew[lane] = f2bf(o1);
+                    knew[lane + 64] = f2bf(o2);
+                    const int opage = page_table[(size_t)m.seq * max_pages + own_pg];
+                    uint16_t* base = (uint16_t*)kcache + ((size_t)kvh * total_pages + opage) * (MTTS_PAGE * MTTS_HD);
+                    const int tok = m.pos & 63;        // element (tok, d) at ((d/8)*64 + tok)*8 + d%8
+                    base[(((lane >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o1);
+                    base[((((lane + 64) >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o2);
+                }
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
-        }
-    }
-    if (FUSED) {
-        const bool own = (own_pg >> 2) == (int)blockIdx.x;
-        for (int hh = wave; hh < G + (own ? 1 : 0); hh += 4) {
-            const bool isk = hh == G;
-            float a, b, o1, o2;
-            const FuseVec fv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
-            fuse_reduce(f, r, (isk ? nq + kvh : kvh * G + hh) * MTTS_HD, lane, a, b);
-            fuse_norm_rope(f, fv, a, b, o1, o2);
-            if (!isk) {
-                ((uint16_t*)qs[hh])[lane] = f2bf(o1);
-                ((uint16_t*)qs[hh])[lane + 64] = f2bf(o2);
-            } else {
-                knew[lane] = f2bf(o1);
-                knew[lane + 64] = f2bf(o2);
-                const int page = page_table[(size_t)m.seq * max_pages + own_pg];
-                uint16_t* base = (uint16_t*)kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD);
-                const int tok = m.pos & 63;        // element (tok, d) at ((d/8)*64 + tok)*8 + d%8
-                base[(((lane >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o1);
-                base[((((lane + 64) >> 3) * 64) + tok) * 8 + (lane & 7)] = f2bf(o2);
+            for (int i = 0; i < (G * MTTS_HD / 2 + 255) / 256; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                if (idx < G * MTTS_HD / 2) (&qs[0][0])[idx] = qreg[i];      // heads kvh*G .. +G-1 are contiguous in qbuf
             }
         }
-    } else {
-        for (int i = threadIdx.x; i < G * MTTS_HD / 2; i += 256) {
-            int g = i / (MTTS_HD / 2), d2 = i % (MTTS_HD / 2);
-            qs[g][d2] = ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G + g) * (MTTS_HD / 2) + d2];
-        }
-    }
-    __syncthreads();
-    if (pg >= npages) return;
-    if (FUSED && pg == own_pg && lane == (m.pos & 63)) {      // this lane's token is the new one: take its K from LDS
+        lds_barrier();                                // (not __syncthreads: its fence would wait for the page loads in flight)
+    };
+    // rounding points, the page's scores and its softmax statistics
+    auto finish = [&](const float* acc) {
+        const int tok = pg * MTTS_PAGE + lane;
+        const bool valid = tok < len;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) kv[j] = *(const u32x4_t*)&knew[8 * j];
-    }
-    bool qok = true;
-    if (PK && packed) {                               // the page's K is k 2^-s per dim: this wave's q becomes q 2^s (exact, or flagged)
-        const uint32_t sh = kv[12].z;                 // shifts of dims 2 lane, 2 lane + 1
+        for (int g = 0; g < G; ++g) {
+            const int h = kvh * G + g;
+            float sc = rbf(rbf(acc[g]) * scale);
+            if (valid) scores[((size_t)r * nq + h) * Lmax + tok] = f2bf(sc);
+            float mx = wave_max(valid ? sc : -INFINITY);
+            float e = valid ? expf(sc - mx) : 0.f;
+            float sm = wave_sum(e);
+            if (lane == 0) {
+                float* st = stats + (((size_t)r * nq + h) * max_pages + pg) * 2;
+                st[0] = mx;
+                st[1] = sm;
+            }
+        }
+    };
+    // v_dot2c_f32_bf16: two bf16 products per lane-op, fp32 accumulate.  q is read as a wave-uniform (broadcast) 16-byte
+    // LDS word per 8 dims.  `kv` = the bf16 page (16 units per lane), already requested.
+    auto raw_dots = [&](u32x4_t (&kv)[16]) {
+        if (FUSED && pg == own_pg && lane == (m.pos & 63)) {      // this lane's token is the new one: take its K from LDS
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kv[j] = *(const u32x4_t*)&knew[8 * j];
+        }
+        float acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
+                acc[g] = dot2bf(kv[j].x, q.x, acc[g]);
+                acc[g] = dot2bf(kv[j].y, q.y, acc[g]);
+                acc[g] = dot2bf(kv[j].z, q.z, acc[g]);
+                acc[g] = dot2bf(kv[j].w, q.w, acc[g]);
+            }
+            // (every chain ends here: otherwise the optimiser runs the heads one after the other and keeps more alive)
+#pragma unroll
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the q reads from being hoisted into 100s of VGPRs
+        }
+        finish(acc);
+    };
+
+    if (PK && pg < own_pg) {                          // (wave-uniform) a complete page: its sealed form
+        u32x4_t pk[MTTS_PKU];
+        const u32x4_t* pp = kpack + ((size_t)kvh * total_pages + page) * (MTTS_PKU * 64) + lane;
+        // in the order the dot products need them: the dictionary, then per 4 units of work their nibble unit and their
+        // two low-byte units
+#pragma unroll
+        for (int j = 0; j < MTTS_PKU; ++j) pk[pk_order(j)] = __builtin_nontemporal_load(pp + pk_order(j) * 64);
+        stage_q();
+        // the page's K is k 2^-s per dim: this wave's q becomes q 2^s (exact, or flagged)
+        bool qok = true;
+        const uint32_t sh = pk[12].z;                 // shifts of dims 2 lane, 2 lane + 1
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const uint32_t qd = qs[g][lane];
@@ -424,25 +484,23 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
                 }
                 out |= b << (16 * h);
             }
-            qw[wave][g][lane] = out;
+            qw[PK ? wave : 0][g][lane] = out;
         }
         __builtin_amdgcn_wave_barrier();
-    }
-    if (PK && packed && __any(kv[12].w != 0u || !qok)) {      // a row of this page (or this q) did not fit: take the bf16 page
-        packed = false;
+        if (__any(pk[12].w != 0u || !qok)) {          // a row of this page (or this q) did not fit: take the bf16 page
+            u32x4_t kv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
-    }
-    float acc[G];
+            for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+            raw_dots(kv);
+            return;
+        }
+        float acc[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = 0.f;
-    // v_dot2c_f32_bf16: two bf16 products per lane-op, fp32 accumulate, no unpacking.
-    // q is read as a wave-uniform (broadcast) 16-byte LDS word per 8 dims.
-    if (PK && packed) {
+        for (int g = 0; g < G; ++g) acc[g] = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             uint32_t w[4];
-            pk_unit(kv, j, w);
+            pk_unit(pk, j, w);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const u32x4_t q = *(const u32x4_t*)&qw[PK ? wave : 0][g][4 * j];
@@ -451,38 +509,18 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
                 acc[g] = dot2bf(w[2], q.z, acc[g]);
                 acc[g] = dot2bf(w[3], q.w, acc[g]);
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const u32x4_t q = *(const u32x4_t*)&qs[g][4 * j];
-                acc[g] = dot2bf(kv[j].x, q.x, acc[g]);
-                acc[g] = dot2bf(kv[j].y, q.y, acc[g]);
-                acc[g] = dot2bf(kv[j].z, q.z, acc[g]);
-                acc[g] = dot2bf(kv[j].w, q.w, acc[g]);
-            }
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the q reads from being hoisted into 100s of VGPRs
-        }
-    }
-    const int tok = pg * MTTS_PAGE + lane;
-    const bool valid = tok < len;
-    const int Lmax = max_pages * MTTS_PAGE;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int h = kvh * G + g;
-        float s = rbf(rbf(acc[g]) * scale);
-        if (valid) scores[((size_t)r * nq + h) * Lmax + tok] = f2bf(s);
-        float mx = wave_max(valid ? s : -INFINITY);
-        float e = valid ? expf(s - mx) : 0.f;
-        float sm = wave_sum(e);
-        if (lane == 0) {
-            float* st = stats + (((size_t)r * nq + h) * max_pages + pg) * 2;
-            st[0] = mx;
-            st[1] = sm;
-        }
+        finish(acc);
+    } else {                                          // the page being filled (or an engine without sealed pages): bf16
+        u32x4_t kv[16];                              // (a wave past the row's last page reads page 0 and drops it: no branch,
+#pragma unroll                                    //  so the wait counts below stay exact)
+        for (int j = 0; j < 16; ++j) kv[j] = __builtin_nontemporal_load(kp + j * 64);
+        stage_q();
+        if (pg >= npages) return;
+        raw_dots(kv);
     }
 }
 
@@ -544,7 +582,7 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
         if (packed) {
             const u32x4_t* pp = vpack + ((size_t)kvh * total_pages + page) * (MTTS_PKU * 64) + lane;
 #pragma unroll
-            for (int it = 0; it < MTTS_PKU; ++it) vv[it] = __builtin_nontemporal_load(pp + it * 64);
+            for (int it = 0; it < MTTS_PKU; ++it) vv[pk_order(it)] = __builtin_nontemporal_load(pp + pk_order(it) * 64);
         } else {
 #pragma unroll
             for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
