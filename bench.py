@@ -488,12 +488,16 @@ def main():
         # file of the round that last touched csrc/attn.hip (r03: sealed pages, template arguments <G, fused, sealed>).
         traffic, traffic_src = None, None
         sealed = bool(kv_pack and kv_pack["k_layers_on"] == cfg["num_hidden_layers"] and kv_pack["v_layers_on"] == cfg["num_hidden_layers"])
-        for cand, key in (("r03_pmc_attention.json", dom + ("<2, false, true>" if sealed else "<2, false, false>")),):
+        for cand in ("r03_pmc_attention.json",):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
-                if B == 32 and L == 4096 and not args.layers:
-                    traffic = pmc[key]["hbm_bytes_per_launch"]   # GQA group 2, separate q/k/v epilogue (the launch at this size)
-                    traffic_src = "profiles/" + cand
+                if B == 32 and L == 4096 and not args.layers and sealed:
+                    # the file holds the variants that run at this size (GQA group 2; template arguments after the group:
+                    # fused q/k/v epilogue, sealed pages, ...): the full-context launches are the ones with the most calls
+                    keys = [k for k in pmc if k.startswith(dom + "<2,")]
+                    key = max(keys, key=lambda k: pmc[k]["launches"])
+                    traffic = pmc[key]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + cand + " : " + key
                     break
             except Exception:
                 traffic = None

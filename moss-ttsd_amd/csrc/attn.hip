@@ -322,6 +322,27 @@ __device__ __forceinline__ void fuse_reduce(const QkvFuse& f, int r, int col, in
     b = rbf(b);
 }
 
+// The same in two steps for up to 8 slabs (the usual split): request now, add later -- so that the requests can go out
+// BEFORE a page's loads (loads return in order) and the sums run while the page is in flight.
+__device__ __forceinline__ void fuse_reduce_request(const QkvFuse& f, int r, int col, int lane, float (&ta)[8], float (&tb)[8]) {
+    const size_t kstride = (size_t)MTTS_PFCAP * f.Npad;
+    const float* p0 = f.partial + (size_t)r * f.Npad + col + lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* pk = p0 + (size_t)min(j, f.ksplit - 1) * kstride;
+        ta[j] = pk[0];
+        tb[j] = pk[64];
+    }
+}
+__device__ __forceinline__ void fuse_reduce_sum(const QkvFuse& f, const float (&ta)[8], const float (&tb)[8], float& a, float& b) {
+    a = ta[0]; b = tb[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+        if (j < f.ksplit) { a += ta[j]; b += tb[j]; }
+    a = rbf(a);
+    b = rbf(b);
+}
+
 // per-head RMSNorm + RoPE of one q or k head held as (a = x[l], b = x[l+64]) across a wave (qkv_post_kernel's math).
 // The norm weights and the RoPE row are loaded before the slabs are waited for (one memory round trip, not two).
 struct FuseVec { float w0, w1, c, s; };
@@ -376,18 +397,34 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
             qreg[i] = idx < G * MTTS_HD / 2 ? ((const uint32_t*)qbuf)[((size_t)r * nq + kvh * G) * (MTTS_HD / 2) + idx] : 0u;
         }
     }
+    // fused epilogue: this wave's head (q head `wave`, or the new K row in the block that owns the step's page) has its
+    // split-K slabs, norm weights and RoPE row requested here, before the page, for the same reason
+    const bool own = FUSED && (own_pg >> 2) == (int)blockIdx.x;
+    const bool pre = FUSED && f.ksplit <= 8 && wave < G + (own ? 1 : 0);
+    float pta[8], ptb[8];
+    FuseVec pfv{0.f, 0.f, 0.f, 0.f};
+    if (pre) {
+        const bool isk = wave == G;
+        pfv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
+        fuse_reduce_request(f, r, (isk ? nq + kvh : kvh * G + wave) * MTTS_HD, lane, pta, ptb);
+    }
     const int page = pg < npages ? page_table[(size_t)m.seq * max_pages + pg] : 0;
     const u32x4_t* kp = kcache + ((size_t)kvh * total_pages + page) * (MTTS_PAGE * MTTS_HD / 8) + lane;
 
     // q (and, in the block that holds the step's own page, the new K row) into LDS; then the block barrier
     auto stage_q = [&]() {
         if (FUSED) {
-            const bool own = (own_pg >> 2) == (int)blockIdx.x;
             for (int hh = wave; hh < G + (own ? 1 : 0); hh += 4) {
                 const bool isk = hh == G;
                 float a, b, o1, o2;
-                const FuseVec fv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
-                fuse_reduce(f, r, (isk ? nq + kvh : kvh * G + hh) * MTTS_HD, lane, a, b);
+                FuseVec fv;
+                if (pre && hh == wave) {                  // requested before the page
+                    fv = pfv;
+                    fuse_reduce_sum(f, pta, ptb, a, b);
+                } else {
+                    fv = fuse_load_vec(f, isk ? f.knorm_w : f.qnorm_w, m.pos, lane);
+                    fuse_reduce(f, r, (isk ? nq + kvh : kvh * G + hh) * MTTS_HD, lane, a, b);
+                }
                 fuse_norm_rope(f, fv, a, b, o1, o2);
                 if (!isk) {
                     ((uint16_t*)qs[hh])[lane] = f2bf(o1);
@@ -588,11 +625,16 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
             for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
         }
     };
-    if (pg < npages) load_page();
+    // fused epilogue: the wave that owns the step's page requests the new V row's split-K slabs before its page (SF)
     const bool own_wave = FUSED && own_pg >= pg && own_pg < pg + ATT_PB / PV_WAVES;       // one wave per (row, kv head)
+    const bool pre_v = SF && own_wave && f.ksplit <= 8;
+    float vta[8], vtb[8];
+    if (pre_v) fuse_reduce_request(f, r, (nq + nkv + kvh) * MTTS_HD, lane, vta, vtb);
+    if (pg < npages) load_page();
     if (own_wave) {
         float a, b;
-        fuse_reduce(f, r, (nq + nkv + kvh) * MTTS_HD, lane, a, b);
+        if (pre_v) fuse_reduce_sum(f, vta, vtb, a, b);
+        else fuse_reduce(f, r, (nq + nkv + kvh) * MTTS_HD, lane, a, b);
         vnew[lane] = f2bf(a);
         vnew[lane + 64] = f2bf(b);
         const int page = page_table[(size_t)m.seq * max_pages + own_pg];

@@ -216,7 +216,7 @@ struct MttsEngine {
     unsigned long long *d_seal_cnt = nullptr, *h_seal_cnt = nullptr;
     std::vector<char> pack_k_on, pack_v_on;
     int pack_min_work = 512;            // sealed reads from this many rows x KV pages up (MTTS_KV_PACK_MIN)
-    int fuse_qkv_max = 1024;            // decode: q/k/v epilogue inside the attention kernels while rows x KV pages <= this
+    int fuse_qkv_max = 2560;            // decode: q/k/v epilogue inside the attention kernels while rows x KV pages <= this (round 3: 1024 -> 2560 = 32 rows x 80 pages, once its loads go out before the page's: wins at 32 x 64, loses at 64 x 64)
     int pf_mfma_pages = 0;              // prefill attention: tile-sharing MFMA kernels from this many KV pages up (0 = always; a dialogue's numerics must not depend on its batch)
     // profiling
     bool prof = false;
@@ -836,7 +836,7 @@ static int forward_rows(MttsEngine* e, const int32_t* d_tokens, const RowMeta* d
         // decode rows (one dialogue each): the q/k/v epilogue runs inside the attention kernels; prefill passes
         // need every K/V row of the pass in the cache before any of its attention runs, so they keep the launch
         // (fused where it pays: every attention block repeats the q epilogue, which costs more than the saved launch
-        // once rows x pages is large -- measured break-even around 32 rows x 32 pages; the results are bit-identical)
+        // once rows x pages is large -- break-even between 32 x 64 and 64 x 64 rows x pages since round 3; the results are bit-identical)
         const bool fused = heads == 1 && e->B * pages_bound <= e->fuse_qkv_max;
         const QkvFuse fz{e->partial, ks_qkv, e->qkv_rows, (const uint16_t*)l.qn, (const uint16_t*)l.kn,
                          (const uint16_t*)e->rope_cos, (const uint16_t*)e->rope_sin, eps};
