@@ -481,7 +481,17 @@ int32_t mtts_engine_create(const MttsConfig* c, int32_t device, MttsEngine** out
         TRY(dalloc((uint16_t**)&e->kcache, e->layer_stride * e->L));
         TRY(dalloc((uint16_t**)&e->vcache, e->layer_stride * e->L));
         if (e->kv_pack) {
+            // the second pool is an optimisation: when the card cannot hold it beside everything else (a very large
+            // kv_pool_pages), the engine runs on bf16 pages alone instead of failing
             e->pk_layer_stride = (size_t)e->total_pages * e->nkv * MTTS_PKU * 64 * 16;
+            size_t free_b = 0, total_b = 0;
+            const size_t need = 2 * e->pk_layer_stride * e->L;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)8 << 30) > free_b) {
+                fprintf(stderr, "mtts: sealed KV pages off: %.1f GB needed, %.1f GB free (8 GB kept for the run)\n", need / 1e9, free_b / 1e9);
+                e->kv_pack = 0;
+            }
+        }
+        if (e->kv_pack) {
             TRY(dalloc((uint8_t**)&e->kpack, e->pk_layer_stride * e->L));
             TRY(dalloc((uint8_t**)&e->vpack, e->pk_layer_stride * e->L));
             TRY(dalloc(&e->d_seal_cnt, (size_t)e->L * 4));
