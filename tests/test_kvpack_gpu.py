@@ -15,6 +15,7 @@ torch = pytest.importorskip("torch")
 
 from mtts import capi, synth  # noqa: E402
 from oracle import asteroid_oracle as ao  # noqa: E402
+from oracle import kv_seal_oracle as ks  # noqa: E402
 
 
 def _bf16_bits(x):
@@ -110,6 +111,35 @@ def test_sealed_k_pages_rescale_each_dim_by_a_power_of_two_exactly():
     back = np.where(nz, (got.astype(np.int32) + (sh[:, None, :] << 7)) & 0xffff, got).astype(np.uint16)
     assert np.array_equal(back[fits], v[fits])
     assert (_seal(v, as_k=0)[:, 12, :, 12:16].view(np.uint32)[..., 0] != 0).mean() > 0.9    # without the rescale nothing fits
+
+
+@pytest.mark.parametrize("as_k", [0, 1])
+def test_hip_sealer_equals_the_format_oracle_byte_for_byte(as_k):
+    """csrc/attn.hip: seal_lane / seal_lane_k against oracle/kv_seal_oracle.py (the format's specification made
+    executable): every byte of every lane that fits, and the dictionary / shifts / flag unit of every lane."""
+    rng = np.random.default_rng(21 + as_k)
+    P = 10
+    x = rng.standard_normal((P, 64, 128)).astype(np.float32)
+    x[1] *= (2.0 ** rng.integers(-12, 13, (1, 128))).astype(np.float32)
+    x[2] *= (2.0 ** rng.integers(-3, 4, (64, 128))).astype(np.float32)
+    x[3, :, ::9] = 0.0
+    x[4] *= 1e-30
+    x[5] *= 1e30
+    v = _bf16_bits(x)
+    v[6] = rng.integers(0, 1 << 16, (64, 128))
+    v[7, 5, 17] = 0x0002
+    v[7, 9, 3] = 0x7fc0
+    v[8] = 0
+    got = _seal(v, as_k=as_k)                                    # [P, 13, 64, 16]
+    nfit = 0
+    for pg in range(P):
+        want, fit = ks.seal(v[pg], as_k=bool(as_k))
+        assert np.array_equal(got[pg, 12], want[12]), pg         # dictionary, shifts, flag: every lane
+        assert np.array_equal(got[pg][:, fit, :], want[:, fit, :]), pg
+        back, fit2 = ks.unseal(got[pg], as_k=bool(as_k))
+        assert np.array_equal(fit, fit2) and np.array_equal(back[fit], v[pg][fit])
+        nfit += int(fit.sum())
+    assert nfit > 0.5 * P * 64
 
 
 @pytest.mark.parametrize("nq,nkv", [(4, 2), (8, 2), (4, 4)])
