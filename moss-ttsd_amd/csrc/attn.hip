@@ -10,10 +10,15 @@
 //   combine:              sum of partial O over chunks -> bf16, X-fragment layout
 // K and V are each read exactly once; scores are 2 B per (head, token) of scratch.
 //
-// HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.
+// HBM bound.  Algorithmic bytes per (row, layer) = len * nkv * 128 * 2 B * 2.  Since round 3 the decode passes read
+// every COMPLETE page in a lossless 13-bit form ("sealed pages", below): 13/16 of those bytes, the same bits out.
+// Two rules shape the decode kernels: a wave's loads return IN ORDER, so whatever is small and needed first (q, the
+// softmax statistics, a page's scores, the fused epilogue's operands, a sealed page's dictionary) is requested before
+// what is large; and nothing on the way may wait for "all loads" (`__syncthreads()` does: lds_barrier()).
 #include "common.h"
 #include <cstdlib>
-// waves per SIMD the sealed-page kernels are compiled for (register budget 512 / N); 0 = the compiler's choice
+// (tuning aid, tools/ab_build.sh: waves per SIMD the sealed-page kernels are compiled for; 0 = the compiler's choice --
+//  5 was measured and lost, profiles/r03_kv_pack_ab.txt item 4)
 #ifndef MTTS_PK_WAVES
 #define MTTS_PK_WAVES 0
 #endif
