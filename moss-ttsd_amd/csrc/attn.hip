@@ -188,27 +188,12 @@ __device__ __forceinline__ void seal_count(bool fit, unsigned long long* __restr
     if (cnt && lane == 0) atomicAdd(cnt + layer * 4 + wave * 2 + (all ? 0 : 1), 1ull);
 }
 
-// Seal the page a row's token has just completed ((pos & 63) == 63), for every layer and kv head: grid = (R, nkv, L),
-// block 128 = the K wave and the V wave.  Runs at the end of a forward pass (decode step or prefill pass alike).
-__global__ __launch_bounds__(128) void kv_seal_rows_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
-                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack,
-                                                           const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta,
-                                                           int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
-                                                           unsigned long long* __restrict__ cnt) {
-    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
-    const RowMeta m = meta[blockIdx.x];
-    if (m.seq < 0 || (m.pos & 63) != 63) return;
-    const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int page = page_table[(size_t)m.seq * max_pages + (m.pos >> 6)];
-    const size_t pi = (size_t)kvh * total_pages + page;
-    const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                                      vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
-                          : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                                        kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
-    seal_count(fit, cnt, layer, wave, lane);
-}
-// The same for a prefill pass (thousands of rows, one in 64 completes a page): a block looks at 64 rows and seals what
-// it finds.  grid = (ceil(R / 64), nkv, L), block 128.
+// Seal the pages that the rows of a forward pass have just completed ((pos & 63) == 63), for every layer and kv head, at
+// the end of the pass (decode step -- it is in the step's graph -- or prefill pass alike).  A block looks at 64 rows and
+// seals what it finds, the K wave and the V wave side by side: grid = (ceil(R / 64), nkv, L), block 128.  (One block
+// per ROW was the first form: 7 168 blocks of 300 registers and 8 KiB of LDS that look at their row and leave cost
+// 15 us in every decode step; 224 blocks cost 2-3, and a batch whose rows all complete a page in the same step pays
+// 32 pages in a row once in 64 steps.)
 __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __restrict__ kcache, const u32x4_t* __restrict__ vcache,
                                                            u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack,
                                                            const int32_t* __restrict__ page_table, const RowMeta* __restrict__ meta, int R,
@@ -285,13 +270,8 @@ void launch_kv_pack_count(const void* kpack, const void* vpack, const int32_t* p
 void launch_kv_seal_rows(const void* kcache, const void* vcache, void* kpack, void* vpack, const int32_t* page_table,
                          const RowMeta* meta, int R, int max_pages, int total_pages, int nkv, int L, unsigned long long* cnt, hipStream_t st) {
     const size_t raw_layer = (size_t)total_pages * nkv * (MTTS_PAGE * MTTS_HD / 8), pk_layer = (size_t)total_pages * nkv * (MTTS_PKU * 64);
-    if (R > MTTS_RCAP) {                               // a prefill pass
-        hipLaunchKernelGGL(kv_seal_scan_kernel, dim3((R + 63) / 64, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
-                           (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, R, max_pages, total_pages, raw_layer, pk_layer, cnt);
-        return;
-    }
-    hipLaunchKernelGGL(kv_seal_rows_kernel, dim3(R, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
-                       (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, max_pages, total_pages, raw_layer, pk_layer, cnt);
+    hipLaunchKernelGGL(kv_seal_scan_kernel, dim3((R + 63) / 64, nkv, L), dim3(128), 0, st, (const u32x4_t*)kcache, (const u32x4_t*)vcache,
+                       (u32x4_t*)kpack, (u32x4_t*)vpack, page_table, meta, R, max_pages, total_pages, raw_layer, pk_layer, cnt);
 }
 void launch_kv_seal_all(const void* kcache, const void* vcache, void* kpack, void* vpack, int total_pages, int nkv, int L,
                         unsigned long long* cnt, hipStream_t st) {
