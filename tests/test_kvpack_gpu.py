@@ -250,3 +250,34 @@ def test_k_seals_under_any_k_norm_spread_and_the_read_policy_drops_v_when_v_does
     assert st["k_pages"] >= 2 * 10 * cfg["num_key_value_heads"] * L
     assert st["k_unsealed"] <= 0.1 * st["k_pages"] and st["k_layers_on"] == L, st
     assert st["v_unsealed"] >= 0.9 * st["v_pages"] and st["v_layers_on"] == 0, st
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ragged_prompts_around_page_boundaries_sampled_runs_equal_with_and_without_sealed_pages(monkeypatch, seed):
+    """Prompts of 56..136 real tokens (pages complete during the prefill, at the first decode steps, in the middle of
+    the run), left-padded to one batch, SAMPLED with top-k / top-p / temperature / repetition penalty: every token of
+    every row identical with sealed pages on and off, through page completions at different steps in different rows."""
+    from mtts.engine import Engine
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 300 + seed, emb_row_sigma=0.6, speech_boost=5.0)
+    rng = np.random.default_rng(seed)
+    lens = [56, 57, 63, 64, 65, 120, 121, 136]                 # real tokens incl. the 7 delay slots
+    B, T = len(lens), max(lens)
+    ids = np.full((B, T, 8), 1024, dtype=np.int64)
+    ids[:, :, 0] = rng.integers(0, cfg["vocab_size"] - 10, (B, T))
+    mask = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lens):
+        mask[b, T - n:] = 1
+        ids[b, :T - n, 0] = cfg.get("pad_token_id", 0)
+    layers = [{"top_k": 20, "top_p": 0.9, "temperature": 1.1, "repetition_penalty": 1.05}] * 8
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MTTS_KV_PACK", mode)
+        eng = Engine(cfg, max_batch=B, max_seq_len=512)
+        eng.bind_state_dict(w)
+        outs[mode] = eng.generate(ids, mask, T + 150, layers=layers, do_samples=[True] * 8, seed=77 + seed)
+        if mode == "2":
+            st = eng.kv_pack_stats()
+        eng.close()
+    assert outs["0"].shape == outs["2"].shape and np.array_equal(outs["0"], outs["2"])
+    assert outs["0"].shape[1] > T + 60                          # the rows did run (no early EOS for everyone)
