@@ -281,3 +281,36 @@ def test_ragged_prompts_around_page_boundaries_sampled_runs_equal_with_and_witho
         eng.close()
     assert outs["0"].shape == outs["2"].shape and np.array_equal(outs["0"], outs["2"])
     assert outs["0"].shape[1] > T + 60                          # the rows did run (no early EOS for everyone)
+
+
+def test_continuous_batching_reuses_physical_pages_whose_sealed_copies_are_stale(monkeypatch):
+    """7 dialogues with 70-200-token prompts and 60-130 new tokens through 2 slots and a pool of 14 pages: slots are
+    refilled while the other is mid-flight and physical pages go from one dialogue to the next with the previous owner's
+    sealed copy still in the second pool.  A page is only read sealed once ITS CURRENT owner has completed (and so
+    re-sealed) it: every dialogue's tokens equal its batch-1 run on bf16 pages (sampled, per-dialogue Philox keys)."""
+    from mtts.engine import Engine
+    from mtts.scheduler import ContinuousBatcher
+    cfg = synth.tiny()
+    w = synth.synth_weights(cfg, 193, emb_row_sigma=0.6, speech_boost=5.0)
+    rng = np.random.default_rng(17)
+    prompts, mnts = [], []
+    for i in range(7):
+        n = int(rng.integers(70, 200))
+        raw = np.full((n, 8), 1024, dtype=np.int64)
+        raw[:, 0] = rng.integers(0, 151643, n)
+        prompts.append(synth.shifting_inputs(raw, cfg["pad_token_id"]))
+        mnts.append(int(rng.integers(60, 130)))
+    layers, ds = [dict(top_k=20, top_p=0.9, temperature=1.1)] * 8, [True] * 8
+    monkeypatch.setenv("MTTS_KV_PACK", "2")
+    eng = Engine(cfg, max_batch=2, max_seq_len=512, kv_pool_pages=14)
+    eng.bind_state_dict(w)
+    cb = ContinuousBatcher(eng, slots=2, gen_cap=160, layers=layers, do_samples=ds, steps_per_poll=4)
+    got = cb.run(prompts, mnts, base_seed=90)
+    eng.close()
+    monkeypatch.setenv("MTTS_KV_PACK", "0")
+    solo = Engine(cfg, max_batch=1, max_seq_len=512)
+    solo.bind_state_dict(w)
+    for i, p in enumerate(prompts):
+        alone = solo.generate(p[None], np.ones((1, p.shape[0])), p.shape[0] + mnts[i], layers=layers, do_samples=ds, seed=90 + i)[0]
+        assert got[i].shape == alone.shape and np.array_equal(got[i], alone), i
+    solo.close()
