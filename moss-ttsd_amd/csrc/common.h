@@ -36,15 +36,38 @@ __device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {   // 
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
 
+// Cross-lane moves without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: ~100 cycles per dependent step):
+// DPP reaches lane ^ 1, ^ 2 (quad_perm), ^ 4 (row_shl:4 / row_shr:4 on alternate banks) and ^ 8 (row_ror:8) in one VALU
+// instruction (two for ^ 4).  tools/dpp_probe.hip checks the four partner patterns and the max sequence on the GPU.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1>(v, v); }                  // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E>(v, v); }                  // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor4(float v) { return dpp_f<0x114, 0xf, 0xa>(dpp_f<0x104, 0xf, 0x5>(v, v), v); }
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_f<0x128>(v, v); }                 // row_ror:8
+// Sum over the wave, in every lane: the xor butterfly 32, 16, 8, 4, 2, 1 of rounds 1-2 -- the SAME tree of additions
+// (the sums are bit-identical), its last four levels by DPP.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += lane_xor8(v);
+    v += lane_xor4(v);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
     return v;
 }
+// Max over the wave, in every lane (order does not matter for a max): rows of 16 by DPP, then row_bcast15 / row_bcast31
+// bring the whole wave's max to lane 63, which is broadcast.
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v, v));
+    v = fmaxf(v, dpp_f<0x4E>(v, v));
+    v = fmaxf(v, dpp_f<0x141>(v, v));                 // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v, v));                 // row_mirror
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));            // row_bcast15 into rows 1, 3
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));            // row_bcast31 into rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Packed "fragment" layouts.  A matrix [rows32][K] that feeds
