@@ -725,7 +725,7 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = acc[g][i];
-            v += __shfl_xor(v, 32, 64);
+            v = add_xor32(v);
             if (sub == 0) red[wave][g][dl * 4 + i] = v;
         }
     __syncthreads();
@@ -825,13 +825,13 @@ __global__ __launch_bounds__(256) void attn_prefill_scores_kernel(
                 mx = fmaxf(mx, acc[th][i]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // lanes l and l^32 hold the two halves of a row's tokens
+        mx = max_xor32(mx);           // lanes l and l^32 hold the two halves of a row's tokens
         float sm = 0.f;
 #pragma unroll
         for (int th = 0; th < 2; ++th)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sm += (acc[th][i] > -INFINITY) ? expf(acc[th][i] - mx) : 0.f;
-        sm += __shfl_xor(sm, 32, 64);
+        sm = add_xor32(sm);
         if (lane < 32 && mr.seq >= 0) {
             float* st = stats + (((size_t)row * nq + h) * max_pages + pg) * 2;
             st[0] = mx;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void attn_prefill_pv_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mx = fmaxf(mx, t[j]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_xor32(mx);
             float sm = 0.f;
             for (int p = half; p < rpages; p += 8) {
                 float2 t[4];
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void attn_prefill_pv_kernel(
                 for (int j = 0; j < 4; ++j)
                     if (p + 2 * j < rpages) sm += t[j].y * expf(t[j].x - mx);
             }
-            sm += __shfl_xor(sm, 32, 64);
+            sm = add_xor32(sm);
             M[g] = mx;
             S[g] = sm;
         }

@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
             sacc[i] = v;
             mx = fmaxf(mx, v);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(mx);
         const float m_new = fmaxf(m_run, mx);
         const float corr = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);    // no key yet: nothing to rescale
         float ps = 0.f;
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256) void codec_attn_kernel(const float* __restrict
             sacc[i] = pv;
             ps += pv;
         }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = add_xor32(ps);
         l_run = l_run * corr + ps;
         m_run = m_new;
 #pragma unroll
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256, 2) void codec_attn_packed_kernel(const float* 
         float mx = fmaxf(v[0].x, v[0].y);
 #pragma unroll
         for (int i = 1; i < 8; ++i) mx = fmaxf(fmaxf(mx, v[i].x), v[i].y);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(mx);
         const float m_new = fmaxf(m_run, mx);
         const float corr = (m_run == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: nothing to rescale
         f32x2_t ps2 = {0.f, 0.f};
@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void codec_attn_packed_kernel(const float* 
             ps2 += p2;
         }
         float ps = ps2.x + ps2.y;
-        ps += __shfl_xor(ps, 32, 64);
+        ps = add_xor32(ps);
         l_run = l_run * corr + ps;
         m_run = m_new;
 #pragma unroll

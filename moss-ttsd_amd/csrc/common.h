@@ -47,11 +47,27 @@ __device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1>(v, v); 
 __device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E>(v, v); }                  // quad_perm [2,3,0,1]
 __device__ __forceinline__ float lane_xor4(float v) { return dpp_f<0x114, 0xf, 0xa>(dpp_f<0x104, 0xf, 0x5>(v, v), v); }
 __device__ __forceinline__ float lane_xor8(float v) { return dpp_f<0x128>(v, v); }                 // row_ror:8
+// v[l] + v[l ^ 32] and v[l] + v[l ^ 16] in every lane: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper
+// half (the odd rows) of one copy with the lower half (the even rows) of the other, so the two results are {lo, lo} and
+// {hi, hi} and their sum is the pair sum in both halves (same two operands as v + __shfl_xor(v, 32): same bits).
+typedef unsigned int u32x2s_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float add_xor32(float v) {
+    const u32x2s_t t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+__device__ __forceinline__ float max_xor32(float v) {
+    const u32x2s_t t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ float add_xor16(float v) {
+    const u32x2s_t t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
 // Sum over the wave, in every lane: the xor butterfly 32, 16, 8, 4, 2, 1 of rounds 1-2 -- the SAME tree of additions
-// (the sums are bit-identical), its last four levels by DPP.
+// (the sums are bit-identical) -- without the LDS crossbar: lane swaps for the two upper levels, DPP for the lower four.
 __device__ __forceinline__ float wave_sum(float v) {
-    v += __shfl_xor(v, 32, 64);
-    v += __shfl_xor(v, 16, 64);
+    v = add_xor32(v);
+    v = add_xor16(v);
     v += lane_xor8(v);
     v += lane_xor4(v);
     v += lane_xor2(v);
