@@ -14,7 +14,8 @@
 // every COMPLETE page in a lossless 13-bit form ("sealed pages", below): 13/16 of those bytes, the same bits out.
 // Two rules shape the decode kernels: a wave's loads return IN ORDER, so whatever is small and needed first (q, the
 // softmax statistics, a page's scores, the fused epilogue's operands, a sealed page's dictionary) is requested before
-// what is large; and nothing on the way may wait for "all loads" (`__syncthreads()` does: lds_barrier()).
+// what is large; and nothing on the way may wait for "all loads" -- which the compiler's wait counts do after a JOIN of
+// code paths with different numbers of loads in flight: hence one straight-line body per page form.
 #include "common.h"
 #include <cstdlib>
 // (tuning aid, tools/ab_build.sh: waves per SIMD the sealed-page kernels are compiled for; 0 = the compiler's choice --
@@ -50,9 +51,6 @@ __device__ __forceinline__ void pk_unit(const u32x4_t* pk, int j, uint32_t w[4])
     w[3] = __builtin_amdgcn_perm(HB, L1, 0x07030602u);
 }
 
-// Block barrier for data exchanged through LDS only: __syncthreads() also fences global memory, i.e. waits for every load
-// in flight (vmcnt(0)) -- exactly the page loads that should keep flying across it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // i-th unit to request so that unit j's operands (low (j >> 1), nibbles 8 + (j >> 2), dictionary 12) are complete as
 // early as possible: 12, 8, 0, 1, 9, 2, 3, 10, 4, 5, 11, 6, 7
 __host__ __device__ constexpr int pk_order(int i) { return i == 0 ? 12 : (i - 1) % 3 == 0 ? 8 + (i - 1) / 3 : 2 * ((i - 1) / 3) + (i - 1) % 3 - 1; }
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(256) PK_OCC(PK) void attn_scores_kernel(
                 if (idx < G * MTTS_HD / 2) (&qs[0][0])[idx] = qreg[i];      // heads kvh*G .. +G-1 are contiguous in qbuf
             }
         }
-        lds_barrier();                                // (not __syncthreads: its fence would wait for the page loads in flight)
+        __syncthreads();                              // (waits for LDS only: the page loads keep flying across it)
     };
     // rounding points, the page's scores and its softmax statistics
     auto finish = [&](const float* acc) {
