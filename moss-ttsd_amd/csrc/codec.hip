@@ -1219,18 +1219,24 @@ static int weight_planes_perm(MttsCodec* k, hipStream_t st, const float* W2, lon
     return 0;
 }
 // The fused kernel runs ONE 64-row block per CU at a time (it owns all 160 KiB of LDS), so a call takes
-// ceil(blocks / 256) rounds of ~340 us whatever the last round holds: it beats the two launches (0.0253 us per row) when
-// the last round is nearly full, and from 12 windows per call up in any case (measured 4 .. 32 windows per call,
-// profiles/r03_codec_fused_pw.json: -8 % per window at 16 and 32, +4 % at 8).
+// ceil(blocks / 256) rounds of ~330 us whatever the last round holds, while the two launches cost 0.0253 us per row
+// (414 us per 16 384 rows).  Auto: the full rounds always go to the fused kernel; the last, partial round too when it is
+// at least 78 % full (330 < 0.78 x 414 + two launch overheads), otherwise to the two launches (gemm_planes on a row range).
+// Measured 1 .. 32 windows per call, profiles/r03_codec_fused_pw.json: never slower than the two launches, -8 % per
+// window at 16 and 32.
 static bool fused_pw_pays(long rows, long setting) {
     if (setting >= 0) return setting > 0 && rows >= setting;
-    const long blocks = (rows + 63) / 64, rounds = (blocks + 255) / 256;
-    return rows >= 36000 || (double)blocks / (double)(rounds * 256) >= 0.90;
+    const long blocks = (rows + 63) / 64, last = blocks % 256;
+    return last == 0 || last >= 200;
 }
+// `row0` / `plane_rows`: rows row0 .. row0 + M - 1 of operands whose planes were laid out for `plane_rows` rows (row0 a
+// multiple of 32: a whole number of fragment tiles; 0 / 0 = all of them): the part of a Vocos call the fused kernel leaves.
 static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long a_rows, const float* W, float* C, int M, int N,
                        int K, long lda, long ldc, const float* bias, int act, const float* gamma, const float* res, long ldres,
-                       bool c_planes, long c_rows) {
+                       bool c_planes, long c_rows, long row0 = 0, long plane_rows = 0) {
     (void)a_rows; (void)c_rows; (void)lda;
+    if (!plane_rows) plane_rows = M;
+    if (row0 % 32) return cfail(MTTS_EINVAL, "gemm_planes: row0 must be a multiple of 32");
     if (N % 4) return cfail(MTTS_EINVAL, "gemm_planes: N must be a multiple of 4");
     const int combo = (act == 1) | (gamma ? 2 : 0) | (res ? 4 : 0) | (c_planes ? 8 : 0);          // the kernel's epilogues
     if (combo != 0 && combo != 4 && combo != 6 && combo != 9) return cfail(MTTS_EINVAL, "gemm_planes: no epilogue for flag combination %d", combo);
@@ -1238,9 +1244,11 @@ static int gemm_planes(MttsCodec* k, hipStream_t st, const float* a_planes, long
     const long wn = pad32(N) * (long)K;                      // elements per weight plane
     TRYC(weight_planes(k, st, W, N, K, &wp));
     // activation planes: hi plane first, lo plane pad32(M) rows further (both in fragment order, K = row length)
-    GemmF32Args g{nullptr, nullptr, C, bias, gamma, res, M, N, K, (long)K, (long)K, ldc, ldres, 0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
-                  (const uint16_t*)a_planes, (const uint16_t*)a_planes + pad32(M) * K, wp, wp + wn,
-                  c_planes ? (uint16_t*)C : nullptr, c_planes ? (uint16_t*)C + pad32(M) * ldc : nullptr};
+    const uint16_t* ah = (const uint16_t*)a_planes + row0 * K;
+    uint16_t* ch = c_planes ? (uint16_t*)C + row0 * ldc : nullptr;
+    GemmF32Args g{nullptr, nullptr, c_planes ? C : C + row0 * ldc, bias, gamma, res ? res + row0 * ldres : nullptr, M, N, K, (long)K, (long)K, ldc, ldres,
+                  0, 1.f, act, 1, 0, 0, 0, 0, 0, 0,
+                  ah, ah + pad32(plane_rows) * K, wp, wp + wn, ch, c_planes ? ch + pad32(plane_rows) * ldc : nullptr};
     int code = k->tile ? k->tile : b3t_choose(M, N, K, act);
     if (k->nt_out && combo == 9) g.batch_inner = 2;
     TRYC(b3t_launch(st, g, code));
@@ -1842,13 +1850,23 @@ static int detokenize_async(MttsCodec* k, const int64_t* dev_codes, const int32_
             else
                 hipLaunchKernelGGL(dwconv_ln_kernel, dim3((rows8 + 3) / 4), dim3(256), 0, st, A, dw_w, dw_b, ln_w, ln_b, Cc, B, T8,
                                    vd, 1e-6f, (uint16_t*)Cc + pad32(rows8) * vd);
-            if (vd == 512 && vi == 4096 && fused_pw_pays(rows8, k->fused_pw_rows)) {
-                // pw1 -> GELU -> pw2 in one launch: the 4096-wide intermediate stays on the CU
-                uint16_t *w1p = nullptr, *w2p = nullptr;
-                TRYC(weight_planes(k, st, p1_w, vi, vd, &w1p));
-                TRYC(weight_planes_perm(k, st, p2_w, (long)vd * vi, &w2p));
-                launch_vocos_pw_fused(st, (const uint16_t*)Cc, pad32(rows8) * (long)vd, w1p, p1_b, w2p, (long)vd * vi, p2_b, gam, A, rows8);
-                continue;
+            if (vd == 512 && vi == 4096 && k->fused_pw_rows != 0) {
+                // pw1 -> GELU -> pw2 in one launch: the 4096-wide intermediate stays on the CU.  Either the whole call, or
+                // (auto) its full rounds of 256 blocks with the last, partial round left to the two launches below.
+                long rows_f = fused_pw_pays(rows8, k->fused_pw_rows) ? rows8 : 0;
+                if (!rows_f && k->fused_pw_rows < 0) rows_f = ((rows8 + 63) / 64 / 256) * 256 * 64;
+                if (rows_f) {
+                    uint16_t *w1p = nullptr, *w2p = nullptr;
+                    TRYC(weight_planes(k, st, p1_w, vi, vd, &w1p));
+                    TRYC(weight_planes_perm(k, st, p2_w, (long)vd * vi, &w2p));
+                    launch_vocos_pw_fused(st, (const uint16_t*)Cc, pad32(rows8) * (long)vd, w1p, p1_b, w2p, (long)vd * vi, p2_b, gam, A, (int)rows_f);
+                    if (rows_f < rows8) {
+                        const int rem = rows8 - (int)rows_f;
+                        TRYC(gemm_planes(k, st, Cc, rows8, p1_w, k->big, rem, vi, vd, vd, vi, p1_b, 1, nullptr, nullptr, 0, true, rows8, rows_f, rows8));
+                        TRYC(gemm_planes(k, st, k->big, rows8, p2_w, A, rem, vd, vi, vi, vd, p2_b, 0, gam, A, vd, false, 0, rows_f, rows8));
+                    }
+                    continue;
+                }
             }
             TRYC(gemm_planes(k, st, Cc, rows8, p1_w, k->big, rows8, vi, vd, vd, vi, p1_b, 1, nullptr, nullptr, 0, true, rows8));
             TRYC(gemm_planes(k, st, k->big, rows8, p2_w, A, rows8, vd, vi, vi, vd, p2_b, 0, gam, A, vd, false, 0));   // h += gamma * pw2(..)

@@ -222,6 +222,34 @@ def test_codec_fused_pointwise_kernel_vs_reference_and_two_launch_form(golden_di
     _dump(f"r03_codec_fused_{name}.json", rec)
 
 
+def test_codec_partial_round_split_between_fused_and_two_launch_kernels(golden_dir, monkeypatch):
+    """7 windows in one call = 21 000 rows = 329 blocks of 64: the fused kernel takes the 256 blocks of the full round,
+    the two launches the remaining 73 (rows 16 384 ..: operands addressed inside planes laid out for 21 000 rows).  Every
+    window within 1e-5 RMS of the all-two-launch result, and window 0 within the 1e-4 tolerance of the reference."""
+    from mtts.codec import CodecEngine
+    z, cfg = _codec_case(golden_dir, "codec_full_T375")
+    w = synth_codec.synth_weights(cfg, int(z["seed"]))
+    c0 = synth_codec.synth_codes(cfg, int(z["seed"]) + 1, [375])[0]
+    rng = np.random.default_rng(5)
+    codes = [c0] + [rng.integers(0, 1024, c0.shape).astype(c0.dtype) for _ in range(6)]
+    out = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("MTTS_CODEC_FUSED_PW", raising=False)
+        else:
+            monkeypatch.setenv("MTTS_CODEC_FUSED_PW", mode)
+        eng = CodecEngine(cfg)
+        eng.bind_state_dict(w)
+        out[mode] = [x.cpu().numpy().astype(np.float64) for x in eng.decode([torch.from_numpy(c) for c in codes])]
+        eng.close()
+    difs = [float(np.sqrt(np.mean((a - b) ** 2))) for a, b in zip(out["0"], out[None])]
+    assert max(difs) <= 1e-5, difs
+    assert min(difs[:5]) > 0.0, difs                      # windows of the full round really went through the fused kernel
+    stride = int(z["stride"])
+    ref = z["wav0_sub"].astype(np.float64)
+    assert float(np.sqrt(np.mean((out[None][0][::stride] - ref) ** 2))) <= 1e-4
+
+
 @pytest.mark.parametrize("name", ["codec_enc_full_12s", "codec_enc_full_ragged"])
 def test_encoder_full_depth_exact_ids(golden_dir, name):
     """The two 12-layer OmniAudioEncoders + the 4-layer adapters + down-conv + 8-stage RVQ search against the
