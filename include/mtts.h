@@ -223,11 +223,13 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
  * 8-11 one code nibble per value (byte 4j+k: low nibble = value 8j+k, high nibble = value 8j+4+k; code = sign << 3 | index),
  * unit 12 = 8 dictionary bytes ((bf16 >> 8) & 0x7f, ascending), a 32-bit spare, a 32-bit flag: != 0 = the lane did not fit
  * and the rest of its sealed data is undefined).  Lossless: value = sign << 15 | dictionary[index] << 8 | low byte.
- * as_k = 0: the values as they are (V pages).  as_k = 1 (K pages: lane = token, value i = dim i): dim d is first divided
+ * as_k = 0: the values as they are.  as_k = 1 (K pages: lane = token, value i = dim i): dim d is first divided
  * by 2^s[d], s[d] = (rounded mean of the non-zero exponent fields of dim d over the page's 64 tokens) - 125 (0 for an
- * all-zero dim; clamped to -127..127), lane l
- * keeps s[2l], s[2l+1] as int8 in the low 16 bits of its spare; k = stored value x 2^s[d] exactly (a lane with a denormal,
- * inf / NaN or an exponent that would leave 1..254 is flagged instead). */
+ * all-zero dim; clamped to -127..127), lane l keeps s[2l], s[2l+1] as int8 in the low 16 bits of its spare; k = stored value
+ * x 2^s[d] exactly (a lane with a denormal, inf / NaN or an exponent that would leave 1..254 is flagged instead).
+ * as_k = 2 (V pages: lane = 32 * sub + dl, value 8 it + 2 c + h = token 4 it + 2 sub + h, dim 4 dl + c): token t is first
+ * divided by 2^s[t], s[t] = (rounded mean of the non-zero exponent fields of token t's 128 values) - (the smallest such
+ * mean of the page), 0..127 (0 for an all-zero token); lane t keeps s[t] in the low byte of its spare; the same flags. */
 int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, int32_t as_k, void* stream);
 /* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
 int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,

@@ -111,7 +111,7 @@ __device__ bool seal_encode(const u32x4_t (&v)[16], u32x4_t* __restrict__ pk, ui
     pk[12 * 64] = u32x4_t{(uint32_t)dict, (uint32_t)(dict >> 32), spare, 0u};
     return true;
 }
-// V pages (and the format hook): the lane's values as they are.
+// The format hook's plain form: the lane's values as they are.
 __device__ bool seal_lane(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk) {
     u32x4_t v[16];
 #pragma unroll
@@ -180,6 +180,83 @@ __device__ bool seal_lane_k(const u32x4_t* __restrict__ raw, u32x4_t* __restrict
     }
     return seal_encode(v, pk, ((uint32_t)s0 & 0xffu) | (((uint32_t)s1 & 0xffu) << 8), unfit);
 }
+// V pages: a lane is 4 neighbouring dims of the 32 tokens of one parity (lane = 32 * sub + dl: token pair 2 it + sub in
+// unit it, dims 4 dl .. 4 dl + 3, halves = the pair's two tokens), and what spreads its magnitudes most is the TOKEN (V has
+// no norm: a dialogue's first tokens, sinks, loud and quiet frames).  So each token is first divided by a power of two
+// taken from the page: s[t] = (rounded mean exponent of token t's 128 values) - (the smallest such mean in the page),
+// >= 0, and the reader multiplies the token's PROBABILITY by 2^s[t] before the dot products: p 2^s . v 2^-s is the same
+// fp32 product bit for bit (p <= 1 and s >= 0: p 2^s cannot underflow; a denormal p with s != 0, or a value whose
+// rescaled exponent would leave the normal range, sends the page to its bf16 form).  Lane t keeps s[t] in the low byte
+// of its spare dword (the reader's lane t is the one that computes token t's probability).  `lds` = 8 KiB + 320 B.
+__device__ bool seal_lane_v(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk, uint8_t* __restrict__ lds, int lane) {
+    u32x4_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = raw[j * 64];
+    const int sub = lane >> 5;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* row = (uint32_t*)(lds + lane * 128);            // entry 2 it + h: this lane's 4 dims of token 4 it + 2 sub + h
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t sum = 0u, cnt = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t e = (u4c(v[it], c) >> (7 + 16 * h)) & 0xffu;
+                sum += e;
+                cnt += e ? 1u : 0u;
+            }
+            row[2 * it + h] = sum | (cnt << 16);
+        }
+    __builtin_amdgcn_wave_barrier();
+    int mean;
+    {                                                         // lane t gathers token t from the 32 lanes of its parity
+        const int t = lane, st = (t >> 1) & 1, j = 2 * (t >> 2) + (t & 1);
+        uint32_t tot = 0u, cn = 0u;
+        for (int d = 0; d < 32; ++d) {
+            const uint32_t w = ((const uint32_t*)(lds + (st * 32 + d) * 128))[j];
+            tot += w & 0xffffu;
+            cn += w >> 16;
+        }
+        mean = cn ? (int)((tot + cn / 2) / cn) : 0;          // 0: an all-zero token
+    }
+    int* means = (int*)(lds + 8192);
+    int8_t* sv = (int8_t*)(lds + 8192 + 256);
+    means[lane] = mean;
+    __builtin_amdgcn_wave_barrier();
+    int ref = 255;
+    for (int t = 0; t < 64; ++t) { const int m = means[t]; if (m > 0) ref = min(ref, m); }
+    const int s_own = mean > 0 ? min(mean - ref, 127) : 0;
+    sv[lane] = (int8_t)s_own;
+    __builtin_amdgcn_wave_barrier();
+    bool unfit = false;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int s0 = sv[4 * it + 2 * sub], s1 = sv[4 * it + 2 * sub + 1];
+        uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t out = 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t b = (w[c] >> (16 * h)) & 0xffffu;
+                const int sft = h ? s1 : s0;
+                const int e = (int)((b >> 7) & 0xffu);
+                if (e == 0) {
+                    if ((b & 0x7fu) && sft) unfit = true;
+                } else {
+                    const int e2 = e - sft;
+                    if (e == 255 ? sft != 0 : e2 < 1) unfit = true;
+                    else b = (b - ((uint32_t)sft << 7)) & 0xffffu;
+                }
+                out |= b << (16 * h);
+            }
+            w[c] = out;
+        }
+        v[it] = u32x4_t{w[0], w[1], w[2], w[3]};
+    }
+    return seal_encode(v, pk, (uint32_t)s_own & 0xffu, unfit);
+}
 // counters per layer: {K pages sealed, K pages with a lane that did not fit, the same for V} (the engine's read policy)
 __device__ __forceinline__ void seal_count(bool fit, unsigned long long* __restrict__ cnt, int layer, int wave, int lane) {
     const bool all = !__any(!fit);
@@ -198,6 +275,7 @@ __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __rest
                                                            int max_pages, int total_pages, size_t raw_layer, size_t pk_layer,
                                                            unsigned long long* __restrict__ cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t vlds[8192 + 320];
     const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 64 + lane;
     RowMeta m{-1, 0, 0, 0};
@@ -209,8 +287,8 @@ __global__ __launch_bounds__(128) void kv_seal_scan_kernel(const u32x4_t* __rest
         const int seq = __shfl(m.seq, i, 64), pos = __shfl(m.pos, i, 64);
         const int page = page_table[(size_t)seq * max_pages + (pos >> 6)];
         const size_t pi = (size_t)kvh * total_pages + page;
-        const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                                          vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
+        const bool fit = wave ? seal_lane_v(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                            vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, vlds, lane)
                               : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
                                             kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
         seal_count(fit, cnt, layer, wave, lane);
@@ -221,20 +299,22 @@ __global__ __launch_bounds__(128) void kv_seal_all_kernel(const u32x4_t* __restr
                                                           u32x4_t* __restrict__ kpack, u32x4_t* __restrict__ vpack, int total_pages,
                                                           size_t raw_layer, size_t pk_layer, unsigned long long* __restrict__ cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t vlds[8192 + 320];
     const int kvh = blockIdx.y, layer = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t pi = (size_t)kvh * total_pages + blockIdx.x;
-    const bool fit = wave ? seal_lane(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
-                                      vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane)
+    const bool fit = wave ? seal_lane_v(vcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
+                                        vpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, vlds, lane)
                           : seal_lane_k(kcache + layer * raw_layer + pi * (MTTS_PAGE * MTTS_HD / 8) + lane,
                                         kpack + layer * pk_layer + pi * (MTTS_PKU * 64) + lane, klds, lane);
     seal_count(fit, cnt, layer, wave, lane);
 }
 // Test hook: `npages` pages in a row (bf16 form, 16 KiB each) -> their sealed forms (13 KiB each).  grid = pages, block 64
 __global__ __launch_bounds__(64) void kv_seal_pages_kernel(const u32x4_t* __restrict__ raw, u32x4_t* __restrict__ pk, int as_k) {
-    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t klds[8192 + 320];
     const u32x4_t* src = raw + (size_t)blockIdx.x * (MTTS_PAGE * MTTS_HD / 8) + threadIdx.x;
     u32x4_t* dst = pk + (size_t)blockIdx.x * (MTTS_PKU * 64) + threadIdx.x;
-    if (as_k) seal_lane_k(src, dst, klds, threadIdx.x);
+    if (as_k == 1) seal_lane_k(src, dst, klds, threadIdx.x);
+    else if (as_k == 2) seal_lane_v(src, dst, klds, threadIdx.x);
     else seal_lane(src, dst);
 }
 void launch_kv_seal_pages(const void* raw, void* pk, int npages, int as_k, hipStream_t st) {
@@ -671,8 +751,12 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
         }
         // lane t rounds the probability of token pg*64+t once (bf16, as the reference stores it);
         // the V loop reads pairs back from LDS (same wave: LDS ops are ordered).
+        uint16_t pun[G];                              // the probabilities as the reference rounds them
+        bool pok = true;
         {
             const int tok = pg * MTTS_PAGE + lane;
+            // a sealed V page holds token t's values divided by 2^s[t] (lane t keeps s[t]): its probability takes the 2^s[t]
+            const int sv = (PK && packed) ? (int)(vv[12].z & 0xffu) : 0;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float p = 0.f;
@@ -680,14 +764,23 @@ __global__ __launch_bounds__(PV_WAVES * 64) PK_OCC(PK) void attn_pv_kernel(
                     float s = bf2f(SF ? sraw[g] : scores[((size_t)r * nq + kvh * G + g) * Lmax + tok]);
                     p = expf(s - M[g]) / S[g];
                 }
-                pbuf[wave][g][lane] = f2bf(p);
+                uint32_t pb = f2bf(p);
+                pun[g] = (uint16_t)pb;
+                if (sv && (pb & 0x7fffu)) {
+                    if (((pb >> 7) & 0xffu) == 0u) pok = false;       // a denormal probability cannot be rescaled exactly
+                    else pb += (uint32_t)sv << 7;                     // p <= 1, s <= 127: the exponent field stays <= 254
+                }
+                pbuf[wave][g][lane] = (uint16_t)pb;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (PK && packed && __any(vv[12].w != 0u)) {  // a lane's values did not fit the sealed form: take the bf16 page
+        if (PK && packed && __any(vv[12].w != 0u || !pok)) {  // a lane did not fit the sealed form (or a probability its scale): the bf16 page
             packed = false;
 #pragma unroll
             for (int it = 0; it < 16; ++it) vv[it] = __builtin_nontemporal_load(vp + it * 64);
+#pragma unroll
+            for (int g = 0; g < G; ++g) pbuf[wave][g][lane] = pun[g];
+            __builtin_amdgcn_wave_barrier();
         }
         if (PK && packed) {
 #pragma unroll

@@ -20,7 +20,11 @@ K pages (lane = token, value i = dim i): before the above, dim d is divided by 2
   s[d] = clip(round-half-up(mean of the NON-ZERO exponent fields of dim d over the 64 tokens) - 125, -127, 127), 0 if none;
   lane l keeps s[2l], s[2l+1] (int8) in the first two spare bytes.  A value with exponent field 0 stays as it is (and
   makes its lane unfit if it is a denormal and s != 0); exponent field 255 makes its lane unfit if s != 0; otherwise the
-  new exponent field e - s must lie in 1..254 or the lane is unfit."""
+  new exponent field e - s must lie in 1..254 or the lane is unfit.
+V pages (lane = 32 sub + dl; its value 8 it + 2 c + h is token 4 it + 2 sub + h, dim 4 dl + c): before the above, token t is
+  divided by 2^s[t] with s[t] = min(m[t] - min over tokens with m > 0 of m, 127), m[t] = round-half-up(mean of the non-zero
+  exponent fields of token t's 128 values) (s = 0 for an all-zero token); lane t keeps s[t] in the first spare byte; the same
+  rules for exponent fields 0 and 255, and e - s >= 1.  The reader multiplies token t's probability by 2^s[t]."""
 import numpy as np
 
 
@@ -31,12 +35,40 @@ def k_shifts(page):
     return np.where(cnt > 0, np.clip((tot + cnt // 2) // np.maximum(cnt, 1) - 125, -127, 127), 0).astype(np.int32)
 
 
+def v_token_of():
+    """[64 lanes, 128 values] -> token index of every value of a V page as its lanes see it."""
+    lane = np.arange(64)[:, None]
+    i = np.arange(128)[None, :]
+    return 4 * (i >> 3) + 2 * (lane >> 5) + (i & 1)
+
+
+def v_shifts(page):
+    """page uint16 [64 lanes, 128 values] (V lane order) -> int32 [64] per token."""
+    e = ((page >> 7) & 0xff).astype(np.int64)
+    tok = v_token_of()
+    tot = np.bincount(tok.ravel(), weights=e.ravel(), minlength=64).astype(np.int64)
+    cnt = np.bincount(tok.ravel(), weights=(e > 0).ravel(), minlength=64).astype(np.int64)
+    m = np.where(cnt > 0, (tot + cnt // 2) // np.maximum(cnt, 1), 0)
+    ref = m[m > 0].min() if (m > 0).any() else 255
+    return np.where(m > 0, np.minimum(m - ref, 127), 0).astype(np.int32)
+
+
 def seal(page, as_k=False):
-    """page uint16 [64 lanes, 128 values] -> (sealed uint8 [13, 64, 16], fit bool [64])."""
+    """page uint16 [64 lanes, 128 values] -> (sealed uint8 [13, 64, 16], fit bool [64]).  as_k: False / 0 plain, True / 1 the
+    K form, 2 the V form."""
     v = page.astype(np.int64)
     out = np.zeros((13, 64, 16), dtype=np.uint8)
     unfit = np.zeros(64, dtype=bool)
-    if as_k:
+    if as_k == 2:
+        s = v_shifts(page)[v_token_of()].astype(np.int64)          # per value
+        e = (v >> 7) & 0xff
+        den = (e == 0) & ((v & 0x7f) != 0) & (s != 0)
+        e2 = e - s
+        bad = (e != 0) & np.where(e == 255, s != 0, e2 < 1)
+        unfit = (den | bad).any(axis=1)
+        v = np.where((e != 0) & ~bad, (v - (s << 7)) & 0xffff, v)
+        out[12, :, 8] = v_shifts(page).astype(np.int64) & 0xff
+    elif as_k:
         s = k_shifts(page)
         e = (v >> 7) & 0xff
         den = (e == 0) & ((v & 0x7f) != 0) & (s[None, :] != 0)
@@ -73,7 +105,10 @@ def unseal(sealed, as_k=False):
     fit = sealed[12, :, 12:16].copy().view(np.uint32)[:, 0] == 0
     hi = np.take_along_axis(dic, code & 7, axis=-1)
     v = ((code >> 3) << 15) | (hi << 8) | low
-    if as_k:
+    if as_k == 2:
+        s = sealed[12, :, 8].astype(np.int64)[v_token_of()]
+        v = np.where((v & 0x7fff) != 0, (v + (s << 7)) & 0xffff, v)
+    elif as_k:
         s = sealed[12, :, 8:10].copy().view(np.int8).reshape(128).astype(np.int64)
         v = np.where((v & 0x7fff) != 0, (v + (s[None, :] << 7)) & 0xffff, v)
     return np.where(fit[:, None], v, 0).astype(np.uint16), fit

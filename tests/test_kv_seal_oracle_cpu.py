@@ -50,3 +50,20 @@ def test_k_form_undoes_any_per_dim_scale_and_flags_what_it_cannot_rescale():
     z = np.zeros((64, 128), dtype=np.uint16)                # an empty page seals to an all-zero dictionary, shifts 0
     sealed, fit = ks.seal(z, as_k=True)
     assert fit.all() and not sealed.any()
+
+
+def test_v_form_undoes_per_token_scales():
+    """A V page as its lanes see it (4 dims x 32 tokens per lane) with token norms spread over 16 binades and one very loud
+    token: as it is, few lanes fit; divided per token by a power of two, nearly all do, and the values come back exactly."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((64, 128)).astype(np.float32) * (2.0 ** rng.integers(-8, 9, (64, 1))).astype(np.float32)
+    x[5] *= 2.0 ** 20
+    lanes = x.reshape(16, 2, 2, 32, 4).transpose(1, 3, 0, 4, 2).reshape(64, 128)   # x[token 4 it + 2 sub + h][dim 4 dl + c] -> lane 32 sub + dl, value 8 it + 2 c + h
+    page = _bits(lanes)
+    assert ks.seal(page)[1].mean() < 0.2
+    sealed, fit = ks.seal(page, as_k=2)
+    assert fit.mean() > 0.97
+    back, _ = ks.unseal(sealed, as_k=2)
+    assert np.array_equal(back[fit], page[fit])
+    s = ks.v_shifts(page)
+    assert s.min() == 0 and s[5] >= 15 and np.array_equal(sealed[12, :, 8], s.astype(np.uint8))

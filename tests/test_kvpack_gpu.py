@@ -113,7 +113,7 @@ def test_sealed_k_pages_rescale_each_dim_by_a_power_of_two_exactly():
     assert (_seal(v, as_k=0)[:, 12, :, 12:16].view(np.uint32)[..., 0] != 0).mean() > 0.9    # without the rescale nothing fits
 
 
-@pytest.mark.parametrize("as_k", [0, 1])
+@pytest.mark.parametrize("as_k", [0, 1, 2])
 def test_hip_sealer_equals_the_format_oracle_byte_for_byte(as_k):
     """csrc/attn.hip: seal_lane / seal_lane_k against oracle/kv_seal_oracle.py (the format's specification made
     executable): every byte of every lane that fits, and the dictionary / shifts / flag unit of every lane."""
@@ -122,6 +122,7 @@ def test_hip_sealer_equals_the_format_oracle_byte_for_byte(as_k):
     x = rng.standard_normal((P, 64, 128)).astype(np.float32)
     x[1] *= (2.0 ** rng.integers(-12, 13, (1, 128))).astype(np.float32)
     x[2] *= (2.0 ** rng.integers(-3, 4, (64, 128))).astype(np.float32)
+    x[9] *= (2.0 ** rng.integers(-10, 11, (64, 1))).astype(np.float32)      # (as a V page this is NOT one scale per token: lanes mix tokens)
     x[3, :, ::9] = 0.0
     x[4] *= 1e-30
     x[5] *= 1e30
@@ -133,10 +134,10 @@ def test_hip_sealer_equals_the_format_oracle_byte_for_byte(as_k):
     got = _seal(v, as_k=as_k)                                    # [P, 13, 64, 16]
     nfit = 0
     for pg in range(P):
-        want, fit = ks.seal(v[pg], as_k=bool(as_k))
+        want, fit = ks.seal(v[pg], as_k=as_k)
         assert np.array_equal(got[pg, 12], want[12]), pg         # dictionary, shifts, flag: every lane
         assert np.array_equal(got[pg][:, fit, :], want[:, fit, :]), pg
-        back, fit2 = ks.unseal(got[pg], as_k=bool(as_k))
+        back, fit2 = ks.unseal(got[pg], as_k=as_k)
         assert np.array_equal(fit, fit2) and np.array_equal(back[fit], v[pg][fit])
         nfit += int(fit.sum())
     assert nfit > 0.5 * P * 64
@@ -157,6 +158,8 @@ def test_decode_attention_on_sealed_pages_equals_bf16_pages_bit_for_bit(monkeypa
     V[4, 200:300, :, 8:12] *= (2.0 ** rng.integers(-40, 1, (100, nkv, 4))).astype(np.float32)   # a V lane that cannot
     K[1:, :, :, 3] = 0.0
     K[5] *= (2.0 ** rng.integers(-12, 13, (1, nkv, 128))).astype(np.float32)               # dims on very different scales: seals (rescaled)
+    V[3] *= (2.0 ** rng.integers(-10, 11, (Lmax, 1, 1))).astype(np.float32)                 # tokens on very different scales: V seals (rescaled per token)
+    V[5, 500:520] *= np.float32(2.0 ** -110)                                                 # tokens so quiet that the rescaled loud ones cannot stay normal
     q[2] *= 2.0 ** 60                                                                         # a q the rescale cannot take everywhere: bf16 pages
     K, V = ao.round_bf16(K), ao.round_bf16(V)
     pages = (Lmax + 63) // 64
