@@ -229,7 +229,7 @@ int32_t mtts_k_paged_attn_decode(const void* dev_q, const void* dev_k, const voi
  * x 2^s[d] exactly (a lane with a denormal, inf / NaN or an exponent that would leave 1..254 is flagged instead).
  * as_k = 2 (V pages: lane = 32 * sub + dl, value 8 it + 2 c + h = token 4 it + 2 sub + h, dim 4 dl + c): token t is first
  * divided by 2^s[t], s[t] = (rounded mean of the non-zero exponent fields of token t's 128 values) - (the smallest such
- * mean of the page), 0..127 (0 for an all-zero token); lane t keeps s[t] in the low byte of its spare; the same flags. */
+ * mean of the page), rounded down to even, 0..126 (0 for an all-zero token); lane t keeps s[t] in the low byte of its spare; the same flags. */
 int32_t mtts_k_kv_seal(const void* dev_pages, int32_t npages, void* dev_sealed, int32_t as_k, void* stream);
 /* One sampler call on fp32-from-bf16 logits (HF processors + engine draw). */
 int32_t mtts_k_sample(const void* dev_logits_bf16, int32_t rows, int32_t vocab,

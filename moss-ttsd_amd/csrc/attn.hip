@@ -184,7 +184,7 @@ __device__ bool seal_lane_k(const u32x4_t* __restrict__ raw, u32x4_t* __restrict
 // unit it, dims 4 dl .. 4 dl + 3, halves = the pair's two tokens), and what spreads its magnitudes most is the TOKEN (V has
 // no norm: a dialogue's first tokens, sinks, loud and quiet frames).  So each token is first divided by a power of two
 // taken from the page: s[t] = (rounded mean exponent of token t's 128 values) - (the smallest such mean in the page),
-// >= 0, and the reader multiplies the token's PROBABILITY by 2^s[t] before the dot products: p 2^s . v 2^-s is the same
+// rounded down to even, >= 0, and the reader multiplies the token's PROBABILITY by 2^s[t] before the dot products: p 2^s . v 2^-s is the same
 // fp32 product bit for bit (p <= 1 and s >= 0: p 2^s cannot underflow; a denormal p with s != 0, or a value whose
 // rescaled exponent would leave the normal range, sends the page to its bf16 form).  Lane t keeps s[t] in the low byte
 // of its spare dword (the reader's lane t is the one that computes token t's probability).  `lds` = 8 KiB + 320 B.
@@ -226,7 +226,7 @@ __device__ bool seal_lane_v(const u32x4_t* __restrict__ raw, u32x4_t* __restrict
     __builtin_amdgcn_wave_barrier();
     int ref = 255;
     for (int t = 0; t < 64; ++t) { const int m = means[t]; if (m > 0) ref = min(ref, m); }
-    const int s_own = mean > 0 ? min(mean - ref, 127) : 0;
+    const int s_own = mean > 0 ? min((mean - ref) & ~1, 126) : 0;     // even: the dictionary's entries are PAIRS of binades
     sv[lane] = (int8_t)s_own;
     __builtin_amdgcn_wave_barrier();
     bool unfit = false;

@@ -22,7 +22,7 @@ K pages (lane = token, value i = dim i): before the above, dim d is divided by 2
   makes its lane unfit if it is a denormal and s != 0); exponent field 255 makes its lane unfit if s != 0; otherwise the
   new exponent field e - s must lie in 1..254 or the lane is unfit.
 V pages (lane = 32 sub + dl; its value 8 it + 2 c + h is token 4 it + 2 sub + h, dim 4 dl + c): before the above, token t is
-  divided by 2^s[t] with s[t] = min(m[t] - min over tokens with m > 0 of m, 127), m[t] = round-half-up(mean of the non-zero
+  divided by 2^s[t] with s[t] = min((m[t] - min over tokens with m > 0 of m) rounded down to even, 126), m[t] = round-half-up(mean of the non-zero
   exponent fields of token t's 128 values) (s = 0 for an all-zero token); lane t keeps s[t] in the first spare byte; the same
   rules for exponent fields 0 and 255, and e - s >= 1.  The reader multiplies token t's probability by 2^s[t]."""
 import numpy as np
@@ -50,7 +50,7 @@ def v_shifts(page):
     cnt = np.bincount(tok.ravel(), weights=(e > 0).ravel(), minlength=64).astype(np.int64)
     m = np.where(cnt > 0, (tot + cnt // 2) // np.maximum(cnt, 1), 0)
     ref = m[m > 0].min() if (m > 0).any() else 255
-    return np.where(m > 0, np.minimum(m - ref, 127), 0).astype(np.int32)
+    return np.where(m > 0, np.minimum((m - ref) & ~1, 126), 0).astype(np.int32)
 
 
 def seal(page, as_k=False):
